@@ -1,0 +1,119 @@
+/* include/nbldpc.h -- C ABI of the MI355X non-binary LDPC decode path (libnbldpc_hip.so).
+ *
+ * Drop-in boundary for the reference's message-passing hot path:
+ *
+ *   reference interface (YongonY/NBLDPC)                      replaced by
+ *   --------------------------------------------------------  -----------------------------------------
+ *   bool CNBLDPC::Initial(CSimulation&)   NBLDPC.h:42,         nbl_create()  (graph + GF tables + decoder
+ *        NBLDPC.cpp:140-377 (graph parse, cross indices,                      parameters; device buffers)
+ *        per-algorithm scratch)
+ *   int  CNBLDPC::Decoding(double** L_ch, int* DecodeOutput,   nbl_decode_batch()         host buffers
+ *        int*, int*)        NBLDPC.h:71, NBLDPC.cpp:607-641    nbl_decode_batch_device()  HBM-resident
+ *        -> Decoding_BP :643, Decoding_EMS :778,
+ *           Decoding_TEMS :929
+ *   public members L_post / L_v2c / L_c2v  NBLDPC.h:65-68      nbl_read_state()  (parity tests only)
+ *   ~CNBLDPC                                                   nbl_destroy()
+ *
+ * One reference call decodes ONE codeword on the calling thread; one call here decodes a BATCH of B
+ * independent codewords (the reference's `parallel` lanes, main.cpp:46) on one GPU.
+ * Plain C types only: no exceptions, no exit(); every failure is a negative nbl_status and a message
+ * retrievable with nbl_last_error().  There is NO CPU fallback: without a HIP device nbl_create fails.
+ */
+#ifndef NBLDPC_H
+#define NBLDPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBL_ABI_VERSION 1
+
+/* decode methods: the reference's numbering, Simulation.h:3-9 */
+#define NBL_METHOD_BP   1 /* exact log-domain QSPA, forward/backward */
+#define NBL_METHOD_EMS  2 /* configuration-set EMS, nm/nc truncated   */
+#define NBL_METHOD_TEMS 4 /* trellis EMS                              */
+
+typedef enum nbl_status {
+	NBL_OK = 0,
+	NBL_ERR_ARG = -1,        /* bad argument / inconsistent graph (reference: undefined behaviour or exit(-1)) */
+	NBL_ERR_UNSUPPORTED = -2,/* method 3/5/6/7 (reference prints "not developed" and exits, NBLDPC.cpp:618-638) */
+	NBL_ERR_NO_DEVICE = -3,  /* no HIP device: there is deliberately no CPU path                               */
+	NBL_ERR_HIP = -4,        /* a HIP runtime call failed                                                      */
+	NBL_ERR_NOMEM = -5
+} nbl_status;
+
+/* Tanner graph exactly as the reference's code file lists it (NBLDPC.cpp:147-205), 0-based indices.
+ * Both directions are given because their ORDER is semantically relevant: the order of a check's edges
+ * fixes the floating-point association order and the tie-breaks of every check-node algorithm. */
+typedef struct nbl_code_desc {
+	int32_t N, M, q;            /* CodeLen, ChkLen, GFq                                        */
+	const int32_t *var_deg;     /* [N]  VarDegree                                              */
+	const int32_t *chk_deg;     /* [M]  ChkDegree                                              */
+	const int32_t *var_chk;     /* [E]  VarLink, variable-major                                */
+	const int32_t *var_h;       /* [E]  VarLinkGFe                                             */
+	const int32_t *chk_var;     /* [E]  ChkLink, check-major                                   */
+	const int32_t *chk_h;       /* [E]  ChkLinkGFe                                             */
+} nbl_code_desc;
+
+/* Decoder parameters: the fields CNBLDPC::Initial copies out of CSimulation (NBLDPC.cpp:142-143, 267-304). */
+typedef struct nbl_params {
+	int32_t method;             /* NBL_METHOD_*                                                */
+	int32_t max_iter;           /* sim.maxIter                                                 */
+	int32_t ems_nm, ems_nc;     /* sim.ems_nm, sim.ems_nc                                      */
+	double  ems_factor, ems_offset;
+	int32_t tems_nr, tems_nc;   /* sim.tems_nr, sim.tems_nc                                    */
+	double  tems_factor, tems_offset;
+	int32_t fixed_iters;        /* 0: a codeword stops at its first zero syndrome (reference).   */
+	                            /* 1: every codeword runs max_iter iterations (throughput runs); */
+	                            /*    outputs are frozen at the first zero syndrome either way.  */
+	int32_t poll_every;         /* fixed_iters==0: ask the device every k iterations whether all */
+	                            /* codewords are done (0 = never, run max_iter launches)         */
+	int32_t max_batch;          /* workspace is sized for this many codewords (grows on demand)  */
+} nbl_params;
+
+typedef struct nbl_decoder nbl_decoder;
+
+/* gf_mul: q*q multiplication table, gf_inv: q inverses (gf_inv[0] ignored) -- the tables CGF::Initial loads
+ * from ./SRC/Arith.Table.GF.<q>.txt (GF.cpp:81-113).  Addition must be XOR (checked against gf_mul's
+ * distributivity is not attempted; the reference's tables are polynomial-basis for every q it ships). */
+nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_mul, const uint16_t *gf_inv,
+                      const nbl_params *params, int device, nbl_decoder **out);
+void nbl_destroy(nbl_decoder *dec);
+
+/* L_ch: [B][N][q-1] doubles, L_ch[b][n][a-1] = ln P(x_n=a)/P(x_n=0)  (RX_LLR_SYM, Comm.cpp:340-407).
+ * out_sym: [B][N] decided symbols (DecodeOutput).  converged: [B] 1 = zero syndrome reached (the
+ * reference's return value).  iters: [B] iteration of the first zero syndrome, or max_iter.
+ * converged / iters may be NULL. */
+nbl_status nbl_decode_batch(nbl_decoder *dec, const double *L_ch, int32_t B, int32_t *out_sym,
+                            uint8_t *converged, int32_t *iters);
+
+/* Same, every pointer is DEVICE memory on the decoder's device; work is enqueued on `stream`
+ * (a hipStream_t, NULL = the decoder's own stream) and NOT synchronised -- except when poll_every > 0. */
+nbl_status nbl_decode_batch_device(nbl_decoder *dec, const double *d_L_ch, int32_t B, int32_t *d_out_sym,
+                                   uint8_t *d_converged, int32_t *d_iters, void *stream);
+
+/* Message state of codeword b after the last decode call (host buffers, any may be NULL):
+ * post [N][q-1], v2c [E][q-1], c2v [E][q-1], edges in variable-major order.  For parity tests. */
+nbl_status nbl_read_state(nbl_decoder *dec, int32_t b, double *post, double *v2c, double *c2v);
+
+/* Keep L_post of the last variable-node pass so nbl_read_state can return it (costs N q-vectors of
+ * extra HBM writes per iteration; off by default). */
+nbl_status nbl_set_record_state(nbl_decoder *dec, int32_t on);
+
+/* Per-phase device time of the last decode call in milliseconds (HIP events on the launch stream):
+ * ms[0] variable-node kernels, ms[1] syndrome kernels, ms[2] check-node kernels, ms[3] whole call.
+ * Only filled when profiling was switched on with nbl_set_profiling(dec, 1). */
+nbl_status nbl_set_profiling(nbl_decoder *dec, int32_t on);
+nbl_status nbl_last_timing(nbl_decoder *dec, double ms[4], int64_t launches[3]);
+
+int32_t nbl_abi_version(void);
+const char *nbl_last_error(const nbl_decoder *dec); /* dec may be NULL: error of the last failed nbl_create */
+size_t nbl_workspace_bytes(const nbl_decoder *dec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

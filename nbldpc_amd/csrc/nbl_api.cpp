@@ -1,0 +1,352 @@
+// nbldpc_amd/csrc/nbl_api.cpp -- C ABI (include/nbldpc.h) on top of the HIP kernels.
+//
+// Replaces CNBLDPC::Initial's decoder set-up (NBLDPC.cpp:140-377: graph cross indices, message buffers) and
+// CNBLDPC::Decoding's iteration loop (NBLDPC.cpp:607-641 -> Decoding_BP/EMS/TEMS) for a batch of codewords.
+// No CPU decode path exists in this library: without a HIP device nbl_create() fails.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/nbldpc.h"
+#include "nbl_kernels.h"
+
+static thread_local std::string g_create_error;
+
+struct nbl_decoder {
+	int device = -1;
+	nbl_params prm{};
+	NblGraphDev g{};
+	NblWork w{};
+	std::vector<void *> graph_allocs;
+	int *d_e2c_map = nullptr;   // variable-major edge -> check-major slot (same as v_cpos), for c2v read-back
+	int cap = 0;                // codewords the workspace holds
+	size_t ws_bytes = 0;
+	double *d_Lin = nullptr;    // staging of the host-layout input [cap][N][q-1]
+	uint8_t *d_conv8 = nullptr;
+	hipStream_t stream = nullptr;
+	bool record_state = false;
+	bool profiling = false;
+	hipEvent_t ev[2] = {nullptr, nullptr};
+	double ms[4] = {0, 0, 0, 0};
+	long long launches[3] = {0, 0, 0};
+	int last_B = 0;
+	std::string err;
+};
+
+#define HIP_TRY(dec, call)                                                                         \
+	do {                                                                                           \
+		hipError_t e_ = (call);                                                                    \
+		if (e_ != hipSuccess) {                                                                    \
+			(dec)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+			return NBL_ERR_HIP;                                                                    \
+		}                                                                                          \
+	} while (0)
+
+static int ilog2(int q)
+{
+	int p = 0;
+	while ((1 << p) < q) p++;
+	return p;
+}
+
+template <typename T> static nbl_status upload(nbl_decoder *d, const std::vector<T> &h, const T **dst)
+{
+	void *p = nullptr;
+	HIP_TRY(d, hipMalloc(&p, h.size() * sizeof(T) + 16));
+	d->graph_allocs.push_back(p);
+	HIP_TRY(d, hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+	*dst = (const T *)p;
+	return NBL_OK;
+}
+
+static void free_workspace(nbl_decoder *d)
+{
+	void *ptrs[] = {d->w.Lch, d->w.v2c, d->w.c2v, d->w.post, d->w.dec, d->w.out, d->w.iters, d->w.done, d->d_Lin, d->d_conv8};
+	for (void *p : ptrs)
+		if (p) (void)hipFree(p);
+	d->w.Lch = d->w.v2c = d->w.c2v = d->w.post = nullptr;
+	d->w.dec = d->w.out = d->w.iters = nullptr;
+	d->w.done = nullptr;
+	d->d_Lin = nullptr;
+	d->d_conv8 = nullptr;
+	d->cap = 0;
+	d->ws_bytes = 0;
+}
+
+static nbl_status ensure_workspace(nbl_decoder *d, int B)
+{
+	if (B <= d->cap && (!d->record_state || d->w.post)) return NBL_OK;
+	int cap = B > d->cap ? B : d->cap;
+	free_workspace(d);
+	const size_t q = d->g.q, N = d->g.N, E = d->g.E;
+	size_t bytes = 0;
+	auto alloc = [&](void **p, size_t n) -> hipError_t { bytes += n; return hipMalloc(p, n); };
+	HIP_TRY(d, alloc((void **)&d->w.Lch, (size_t)cap * N * q * 8));
+	HIP_TRY(d, alloc((void **)&d->w.v2c, (size_t)cap * E * q * 8));
+	HIP_TRY(d, alloc((void **)&d->w.c2v, (size_t)cap * E * q * 8));
+	if (d->record_state) HIP_TRY(d, alloc((void **)&d->w.post, (size_t)cap * N * q * 8));
+	HIP_TRY(d, alloc((void **)&d->w.dec, (size_t)cap * N * 4));
+	HIP_TRY(d, alloc((void **)&d->w.out, (size_t)cap * N * 4));
+	HIP_TRY(d, alloc((void **)&d->w.iters, (size_t)cap * 4));
+	HIP_TRY(d, alloc((void **)&d->w.done, (size_t)cap));
+	d->cap = cap;
+	d->ws_bytes = bytes;
+	return NBL_OK;
+}
+
+extern "C" int32_t nbl_abi_version(void) { return NBL_ABI_VERSION; }
+
+extern "C" const char *nbl_last_error(const nbl_decoder *dec) { return dec ? dec->err.c_str() : g_create_error.c_str(); }
+
+extern "C" size_t nbl_workspace_bytes(const nbl_decoder *dec) { return dec ? dec->ws_bytes : 0; }
+
+static nbl_status fail_create(nbl_decoder *d, nbl_status st, const std::string &msg)
+{
+	g_create_error = msg.empty() && d ? d->err : msg;
+	if (d) nbl_destroy(d);
+	return st;
+}
+
+extern "C" nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_mul, const uint16_t *gf_inv,
+                                 const nbl_params *params, int device, nbl_decoder **out)
+{
+	if (!out) return NBL_ERR_ARG;
+	*out = nullptr;
+	if (!code || !gf_mul || !gf_inv || !params) return fail_create(nullptr, NBL_ERR_ARG, "null argument");
+	const int N = code->N, M = code->M, q = code->q;
+	if (N <= 0 || M <= 0 || q < 4 || q > 256 || (q & (q - 1))) return fail_create(nullptr, NBL_ERR_ARG, "unsupported N/M/q (q must be 4..256, power of two)");
+	switch (params->method) {
+	case NBL_METHOD_EMS: case NBL_METHOD_BP: case NBL_METHOD_TEMS: break;
+	default: return fail_create(nullptr, NBL_ERR_UNSUPPORTED, "decode method not supported (reference: 'has not been developed' / OSD / BS-TEMS)");
+	}
+	if (params->max_iter < 0) return fail_create(nullptr, NBL_ERR_ARG, "max_iter < 0");
+	if (params->method == NBL_METHOD_EMS) {
+		// reference: "EMS configuration error! EMS_Nm is too large!" + exit(-1), NBLDPC.cpp:282-286
+		if (params->ems_nm > q) return fail_create(nullptr, NBL_ERR_ARG, "EMS configuration error! EMS_Nm is too large!");
+		if (params->ems_nm < 1 || params->ems_nc < 0) return fail_create(nullptr, NBL_ERR_ARG, "ems_nm < 1 or ems_nc < 0");
+	}
+	if (params->method == NBL_METHOD_TEMS && (params->tems_nr < 1 || params->tems_nc < 0))
+		return fail_create(nullptr, NBL_ERR_ARG, "tems_nr < 1 or tems_nc < 0");
+
+	// ---- host-side graph indices (NBLDPC.cpp:236-263) -------------------------------------------------------
+	std::vector<int> voff(N + 1, 0), coff(M + 1, 0);
+	int maxdv = 0, maxdc = 0;
+	for (int n = 0; n < N; n++) {
+		if (code->var_deg[n] < 1) return fail_create(nullptr, NBL_ERR_ARG, "variable of degree < 1");
+		voff[n + 1] = voff[n] + code->var_deg[n];
+		if (code->var_deg[n] > maxdv) maxdv = code->var_deg[n];
+	}
+	for (int m = 0; m < M; m++) {
+		if (code->chk_deg[m] < 2) return fail_create(nullptr, NBL_ERR_ARG, "check of degree < 2");
+		coff[m + 1] = coff[m] + code->chk_deg[m];
+		if (code->chk_deg[m] > maxdc) maxdc = code->chk_deg[m];
+	}
+	const int E = voff[N];
+	if (coff[M] != E) return fail_create(nullptr, NBL_ERR_ARG, "variable-side and check-side edge counts differ");
+	if (maxdc > NBL_MAXDC || maxdv > NBL_MAXDV) return fail_create(nullptr, NBL_ERR_ARG, "node degree above the supported maximum (8)");
+	std::vector<int> v_cpos(E, -1), c_epos(E, -1), c_var(E), c_h(E), c_hinv(E);
+	for (int ce = 0; ce < E; ce++) {
+		int n = code->chk_var[ce], h = code->chk_h[ce];
+		if (n < 0 || n >= N || h <= 0 || h >= q) return fail_create(nullptr, NBL_ERR_ARG, "check-side edge out of range / zero coefficient");
+		c_var[ce] = n;
+		c_h[ce] = h;
+		c_hinv[ce] = gf_inv[h];
+		if (gf_mul[(size_t)h * q + gf_inv[h]] != 1) return fail_create(nullptr, NBL_ERR_ARG, "gf_inv inconsistent with gf_mul");
+	}
+	for (int n = 0; n < N; n++)
+		for (int e = voff[n]; e < voff[n + 1]; e++) {
+			int m = code->var_chk[e];
+			if (m < 0 || m >= M) return fail_create(nullptr, NBL_ERR_ARG, "variable-side edge out of range");
+			for (int ce = coff[m]; ce < coff[m + 1]; ce++)
+				if (c_var[ce] == n) v_cpos[e] = ce; // last match wins, like VarLinkDc
+			if (v_cpos[e] < 0 || c_h[v_cpos[e]] != code->var_h[e]) return fail_create(nullptr, NBL_ERR_ARG, "variable-side and check-side edge lists disagree");
+		}
+	for (int m = 0; m < M; m++)
+		for (int ce = coff[m]; ce < coff[m + 1]; ce++) {
+			int n = c_var[ce];
+			for (int e = voff[n]; e < voff[n + 1]; e++)
+				if (code->var_chk[e] == m) c_epos[ce] = e; // like ChkLinkDv
+			if (c_epos[ce] < 0) return fail_create(nullptr, NBL_ERR_ARG, "check-side edge without variable-side partner");
+		}
+	// primitive polynomial recovered from the table: x * x^(p-1) = x^p = poly - q
+	const int p = ilog2(q);
+	const int poly = q | gf_mul[(size_t)2 * q + (q >> 1)];
+	for (int a = 0; a < q; a++) {
+		int expect = (a << 1);
+		if (expect & q) expect ^= poly;
+		if (gf_mul[(size_t)a * q + 2] != expect) return fail_create(nullptr, NBL_ERR_ARG, "gf_mul is not a polynomial-basis GF(2^p) table");
+	}
+
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail_create(nullptr, NBL_ERR_NO_DEVICE, "no HIP device (this library has no CPU decode path)");
+	if (device < 0 || device >= ndev) return fail_create(nullptr, NBL_ERR_ARG, "device index out of range");
+
+	nbl_decoder *d = new nbl_decoder();
+	d->device = device;
+	d->prm = *params;
+	if (hipSetDevice(device) != hipSuccess) return fail_create(d, NBL_ERR_HIP, "hipSetDevice failed");
+	if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) return fail_create(d, NBL_ERR_HIP, "hipStreamCreate failed");
+	d->g.N = N; d->g.M = M; d->g.E = E; d->g.q = q; d->g.p = p; d->g.poly = poly; d->g.maxdc = maxdc; d->g.maxdv = maxdv;
+	std::vector<uint8_t> mul8((size_t)q * q);
+	for (size_t i = 0; i < mul8.size(); i++) mul8[i] = (uint8_t)gf_mul[i];
+	nbl_status st;
+	if ((st = upload(d, voff, &d->g.voff)) || (st = upload(d, coff, &d->g.coff)) || (st = upload(d, v_cpos, &d->g.v_cpos)) ||
+	    (st = upload(d, c_epos, &d->g.c_epos)) || (st = upload(d, c_var, &d->g.c_var)) || (st = upload(d, c_h, &d->g.c_h)) ||
+	    (st = upload(d, c_hinv, &d->g.c_hinv)) || (st = upload(d, mul8, &d->g.mul)))
+		return fail_create(d, st, "");
+	d->d_e2c_map = (int *)d->g.v_cpos;
+	void *cnt = nullptr;
+	if (hipMalloc(&cnt, 16) != hipSuccess) return fail_create(d, NBL_ERR_NOMEM, "hipMalloc failed");
+	d->graph_allocs.push_back(cnt);
+	d->w.n_done = (int *)cnt;
+	if (hipEventCreate(&d->ev[0]) != hipSuccess || hipEventCreate(&d->ev[1]) != hipSuccess) return fail_create(d, NBL_ERR_HIP, "hipEventCreate failed");
+	if (params->max_batch > 0 && (st = ensure_workspace(d, params->max_batch))) return fail_create(d, st, "");
+	*out = d;
+	return NBL_OK;
+}
+
+extern "C" void nbl_destroy(nbl_decoder *d)
+{
+	if (!d) return;
+	if (d->device >= 0) (void)hipSetDevice(d->device);
+	if (d->stream) { (void)hipStreamSynchronize(d->stream); }
+	free_workspace(d);
+	for (void *p : d->graph_allocs) (void)hipFree(p);
+	for (auto &e : d->ev)
+		if (e) (void)hipEventDestroy(e);
+	if (d->stream) (void)hipStreamDestroy(d->stream);
+	delete d;
+}
+
+extern "C" nbl_status nbl_set_profiling(nbl_decoder *d, int32_t on)
+{
+	if (!d) return NBL_ERR_ARG;
+	d->profiling = on != 0;
+	return NBL_OK;
+}
+
+extern "C" nbl_status nbl_set_record_state(nbl_decoder *d, int32_t on)
+{
+	if (!d) return NBL_ERR_ARG;
+	d->record_state = on != 0;
+	return NBL_OK;
+}
+
+extern "C" nbl_status nbl_last_timing(nbl_decoder *d, double ms[4], int64_t launches[3])
+{
+	if (!d) return NBL_ERR_ARG;
+	if (ms) memcpy(ms, d->ms, sizeof d->ms);
+	if (launches) for (int i = 0; i < 3; i++) launches[i] = d->launches[i];
+	return NBL_OK;
+}
+
+static nbl_status launch_cn(nbl_decoder *d, const NblRun &r, hipStream_t st)
+{
+	switch (d->prm.method) {
+	case NBL_METHOD_EMS: HIP_TRY(d, nbl_launch_cn_ems(d->g, d->w, r, st)); break;
+	default: d->err = "check-node kernel for this method is not built yet"; return NBL_ERR_UNSUPPORTED;
+	}
+	return NBL_OK;
+}
+
+// The iteration loop of Decoding_BP / _EMS / _TEMS (NBLDPC.cpp:673 / 805 / 973), one launch triple per iteration.
+static nbl_status run_iterations(nbl_decoder *d, const double *d_Lin, int B, hipStream_t st)
+{
+	const nbl_params &p = d->prm;
+	const bool damp = p.method != NBL_METHOD_EMS;
+	NblRun r{};
+	r.B = B;
+	r.fixed_iters = p.fixed_iters;
+	if (p.method == NBL_METHOD_EMS) { r.nm = p.ems_nm; r.nc = p.ems_nc; r.factor = p.ems_factor; r.offset = p.ems_offset; }
+	else { r.nr = p.tems_nr; r.nc = p.tems_nc; r.factor = p.tems_factor; r.offset = p.tems_offset; }
+	r.damp_old = (p.method == NBL_METHOD_BP) ? 0.5 : 0.25;  // NBLDPC.cpp:739 / :1046
+	r.damp_new = (p.method == NBL_METHOD_BP) ? 0.5 : 0.75;
+	d->launches[0] = d->launches[1] = d->launches[2] = 0;
+	if (d->profiling) HIP_TRY(d, hipEventRecord(d->ev[0], st));
+	HIP_TRY(d, nbl_launch_init(d_Lin, d->g, d->w, B, damp ? 1 : 0, st));
+	for (int it = 1; it <= p.max_iter; it++) {
+		r.iter = it;
+		HIP_TRY(d, nbl_launch_vn(d->g, d->w, r, damp, st));
+		HIP_TRY(d, nbl_launch_syn(d->g, d->w, r, st));
+		d->launches[0]++; d->launches[1]++;
+		if (!p.fixed_iters && p.poll_every > 0 && (it % p.poll_every) == 0) {
+			int n_done = 0;
+			HIP_TRY(d, hipMemcpyAsync(&n_done, d->w.n_done, sizeof(int), hipMemcpyDeviceToHost, st));
+			HIP_TRY(d, hipStreamSynchronize(st));
+			if (n_done >= B) break;
+		}
+		nbl_status s = launch_cn(d, r, st);
+		if (s) return s;
+		d->launches[2]++;
+	}
+	if (d->profiling) {
+		HIP_TRY(d, hipEventRecord(d->ev[1], st));
+		HIP_TRY(d, hipEventSynchronize(d->ev[1]));
+		float ms = 0;
+		HIP_TRY(d, hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
+		d->ms[3] = ms;
+	}
+	d->last_B = B;
+	return NBL_OK;
+}
+
+extern "C" nbl_status nbl_decode_batch_device(nbl_decoder *d, const double *d_L_ch, int32_t B, int32_t *d_out_sym,
+                                              uint8_t *d_converged, int32_t *d_iters, void *stream)
+{
+	if (!d || !d_L_ch || !d_out_sym || B < 0) return NBL_ERR_ARG;
+	if (B == 0) return NBL_OK;
+	HIP_TRY(d, hipSetDevice(d->device));
+	hipStream_t st = stream ? (hipStream_t)stream : d->stream;
+	nbl_status s = ensure_workspace(d, B);
+	if (s) return s;
+	if ((s = run_iterations(d, d_L_ch, B, st))) return s;
+	HIP_TRY(d, hipMemcpyAsync(d_out_sym, d->w.out, (size_t)B * d->g.N * 4, hipMemcpyDeviceToDevice, st));
+	if (d_converged) HIP_TRY(d, hipMemcpyAsync(d_converged, d->w.done, (size_t)B, hipMemcpyDeviceToDevice, st));
+	if (d_iters) HIP_TRY(d, hipMemcpyAsync(d_iters, d->w.iters, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+	return NBL_OK;
+}
+
+extern "C" nbl_status nbl_decode_batch(nbl_decoder *d, const double *L_ch, int32_t B, int32_t *out_sym, uint8_t *converged,
+                                       int32_t *iters)
+{
+	if (!d || !L_ch || !out_sym || B < 0) return NBL_ERR_ARG;
+	if (B == 0) return NBL_OK;
+	HIP_TRY(d, hipSetDevice(d->device));
+	nbl_status s = ensure_workspace(d, B);
+	if (s) return s;
+	const size_t in_bytes = (size_t)B * d->g.N * (d->g.q - 1) * 8;
+	if (!d->d_Lin) HIP_TRY(d, hipMalloc((void **)&d->d_Lin, (size_t)d->cap * d->g.N * (d->g.q - 1) * 8));
+	HIP_TRY(d, hipMemcpyAsync(d->d_Lin, L_ch, in_bytes, hipMemcpyHostToDevice, d->stream));
+	if ((s = run_iterations(d, d->d_Lin, B, d->stream))) return s;
+	HIP_TRY(d, hipMemcpyAsync(out_sym, d->w.out, (size_t)B * d->g.N * 4, hipMemcpyDeviceToHost, d->stream));
+	if (converged) HIP_TRY(d, hipMemcpyAsync(converged, d->w.done, (size_t)B, hipMemcpyDeviceToHost, d->stream));
+	if (iters) HIP_TRY(d, hipMemcpyAsync(iters, d->w.iters, (size_t)B * 4, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(d, hipStreamSynchronize(d->stream));
+	return NBL_OK;
+}
+
+extern "C" nbl_status nbl_read_state(nbl_decoder *d, int32_t b, double *post, double *v2c, double *c2v)
+{
+	if (!d || b < 0 || b >= d->last_B) return NBL_ERR_ARG;
+	HIP_TRY(d, hipSetDevice(d->device));
+	const int q = d->g.q, N = d->g.N, E = d->g.E;
+	double *tmp = nullptr;
+	HIP_TRY(d, hipMalloc((void **)&tmp, (size_t)E * (q - 1) * 8));
+	nbl_status rc = NBL_OK;
+	auto grab = [&](const double *src, const int *map, int rows, double *dst) -> nbl_status {
+		HIP_TRY(d, nbl_launch_unpad(src, tmp, map, rows, q, d->stream));
+		HIP_TRY(d, hipMemcpyAsync(dst, tmp, (size_t)rows * (q - 1) * 8, hipMemcpyDeviceToHost, d->stream));
+		HIP_TRY(d, hipStreamSynchronize(d->stream));
+		return NBL_OK;
+	};
+	if (post) {
+		if (!d->w.post) { d->err = "state recording was off during the last decode (nbl_set_record_state)"; rc = NBL_ERR_ARG; }
+		else rc = grab(d->w.post + (size_t)b * N * q, nullptr, N, post);
+	}
+	if (!rc && v2c) rc = grab(d->w.v2c + (size_t)b * E * q, nullptr, E, v2c);
+	if (!rc && c2v) rc = grab(d->w.c2v + (size_t)b * E * q, d->d_e2c_map, E, c2v);
+	(void)hipFree(tmp);
+	return rc;
+}

@@ -1,0 +1,41 @@
+// nbldpc_amd/csrc/nbl_common.h -- shared host/device declarations of the MI355X decode path.
+//
+// HBM layout (all FP64, the reference's message precision):
+//   Lch [B][N][Qp]   channel LLRs, Qp = q rounded up... = q (slot a holds ln P(a)/P(0); slot 0 holds 0.0,
+//                    which is the reference's implicit "symbol 0 carries LLR 0", NBLDPC.cpp:1718)
+//   v2c [B][E][Qp]   variable-to-check messages, variable-major edge order  (L_v2c[col][d], NBLDPC.h:65)
+//   c2v [B][E][Qp]   check-to-variable messages, check-major edge order     (L_c2v[row][d], NBLDPC.h:66)
+//   dec [B][N]       tentative hard decisions of the current iteration
+// A q-vector is one contiguous, 8*q-byte aligned run, so a wave streams it with fully coalesced loads.
+#pragma once
+#include <stdint.h>
+
+#define NBL_WAVE 64
+#define NBL_MAXDC 8   // largest check degree supported by the kernels (reference codes: 4 and 5)
+#define NBL_MAXDV 8
+
+struct NblGraphDev {
+	int N, M, E, q, p, poly, maxdc, maxdv;
+	const int *voff;    // [N+1] variable-major edge offsets
+	const int *coff;    // [M+1] check-major edge offsets
+	const int *v_cpos;  // [E] variable-major edge -> check-major position (its c2v slot)
+	const int *c_epos;  // [E] check-major edge -> variable-major position (its v2c slot)
+	const int *c_var;   // [E] check-major edge -> variable
+	const int *c_h;     // [E] check-major edge coefficient
+	const int *c_hinv;  // [E] inverse coefficient
+	const uint8_t *mul; // [q*q] GF multiplication table (syndrome kernel)
+};
+
+struct NblWork {
+	double *Lch, *v2c, *c2v, *post; // post only when state recording is on
+	int *dec, *out, *iters;
+	uint8_t *done;
+	int *n_done;                    // device counter of converged codewords
+};
+
+struct NblRun {
+	int B, iter, fixed_iters;
+	int nm, nc, nr;
+	double factor, offset;
+	double damp_old, damp_new;
+};

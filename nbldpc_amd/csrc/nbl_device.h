@@ -1,0 +1,109 @@
+// nbldpc_amd/csrc/nbl_device.h -- wave-level device helpers (gfx950, wave64) shared by the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "nbl_common.h"
+
+#define NBL_NEG_INF (-__builtin_huge_val())
+#define NBL_DBL_MAX 1.7976931348623157e308
+
+// lane l of a wave owns symbols a = l + 64*i, i < NS.  For q < 64 only lanes < q own a symbol.
+template <int Q> struct Fld {
+	static constexpr int NS = (Q + 63) / 64;
+	static constexpr int P = (Q == 4) ? 2 : (Q == 8) ? 3 : (Q == 16) ? 4 : (Q == 32) ? 5 : (Q == 64) ? 6 : (Q == 128) ? 7 : 8;
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// v_max_f64 without the canonicalising pre-max hipcc adds in front of fmax() on loaded values
+__device__ __forceinline__ double dmax(double a, double b)
+{
+	double r;
+	asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+__device__ __forceinline__ double dmin(double a, double b)
+{
+	double r;
+	asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+
+__device__ __forceinline__ double read_lane_f64(double v, int lane)
+{
+	int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+	int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+	return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ double uniform_f64(double v)
+{
+	return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+	                        __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ int prefix_count(uint64_t mask)
+{
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+// Multiplication by a wave-uniform GF(2^p) element h, done as a GF(2)-linear map instead of a table:
+// h*a = XOR_{bit i of a} h*x^i.  `lane_part` folds the lane's bits 0..5 once; slot bits 6,7 are constants.
+template <int Q> struct GfMul {
+	int basis[8];
+	int lane_part;
+	__device__ __forceinline__ void init(int h, int poly, int lane)
+	{
+		int x = h;
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			basis[i] = x;
+			x <<= 1;
+			if (x & Q) x ^= poly;
+		}
+		lane_part = 0;
+#pragma unroll
+		for (int i = 0; i < 6; i++)
+			if (i < Fld<Q>::P) lane_part ^= (-((lane >> i) & 1)) & basis[i];
+	}
+	// product with a = lane + 64*slot
+	__device__ __forceinline__ int at_slot(int slot) const
+	{
+		int t = lane_part;
+		if (slot & 1) t ^= basis[6];
+		if (slot & 2) t ^= basis[7];
+		return t;
+	}
+};
+
+// Hard decision of DecideLLRVector (NBLDPC.cpp:1542-1562): running maximum starts at 0, strict '>', so the
+// lowest symbol wins ties and a vector without a positive entry decides 0.  v[i] belongs to a = lane+64 i;
+// slot a = 0 must hold a value <= 0 (it holds 0.0).
+template <int NS> __device__ __forceinline__ int wave_decide(const double (&v)[NS], int lane, int q)
+{
+	double best = 0.0;
+	int arg = 0;
+#pragma unroll
+	for (int i = 0; i < NS; i++) {
+		int a = lane + 64 * i;
+		if (a < q && v[i] > best) { best = v[i]; arg = a; }
+	}
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) {
+		double ob = __shfl_xor(best, off, 64);
+		int oa = __shfl_xor(arg, off, 64);
+		if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+	}
+	return arg;
+}
+
+// check-to-variable shaping, NBLDPC.cpp:903-916 / 1113-1126
+__device__ __forceinline__ double shape_llr(double y, double factor, double offset)
+{
+	if (factor != 1.0) y = y / factor;
+	if (y < -1 * offset) return y + offset;
+	if (y > offset) return y - offset;
+	return 0.0;
+}

@@ -1,0 +1,12 @@
+// nbldpc_amd/csrc/nbl_kernels.h -- host-callable launchers of nbl_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include "nbl_common.h"
+
+hipError_t nbl_launch_init(const double *d_Lin, const NblGraphDev &g, const NblWork &w, int B, int write_v2c, hipStream_t st);
+hipError_t nbl_launch_vn(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool damp, hipStream_t st);
+hipError_t nbl_launch_syn(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);
+hipError_t nbl_launch_cn_ems(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);
+hipError_t nbl_launch_unpad(const double *src, double *dst, const int *map, int rows, int q, hipStream_t st);
+size_t nbl_ems_lds_bytes(const NblGraphDev &g, int nm, int layers);
+int nbl_ems_layers(const NblGraphDev &g, int nc);

@@ -1,0 +1,540 @@
+// nbldpc_amd/csrc/nbl_kernels.hip -- HIP kernels of the NB-LDPC message-passing iteration for gfx950.
+//
+// One iteration of the reference's flooding schedule (NBLDPC.cpp:673-768 / 805-919 / 973-1131) is three launches:
+//   vn_kernel   one wave per (codeword, variable): a-posteriori sum, hard decision, variable-to-check messages
+//   syn_kernel  one wave per codeword: syndrome over GF(q), first-zero-syndrome freeze of the output
+//   cn_*_kernel one wave per (codeword, check): check-node update (EMS / T-EMS / log-QSPA)
+// Everything is FP64 and every floating-point expression keeps the reference's association order; the file
+// is compiled with -ffp-contract=off so no multiply-add is fused.
+#include <hip/hip_runtime.h>
+#include "nbl_device.h"
+#include "nbl_kernels.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// init: host/API layout [B][N][q-1] -> padded [B][N][q] with slot 0 = 0.0; clear c2v; v2c = L_ch
+// (NBLDPC.cpp:649-662 / 781-794 / 934-969)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void init_kernel(const double *__restrict__ Lin, NblGraphDev g, NblWork w, int B, int write_v2c)
+{
+	const int q = g.q;
+	long long total = (long long)B * g.N * q;
+	for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+		int a = (int)(i % q);
+		long long bn = i / q;
+		w.Lch[i] = a ? Lin[bn * (q - 1) + (a - 1)] : 0.0;
+	}
+	long long etotal = (long long)B * g.E * q;
+	for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < etotal; i += (long long)gridDim.x * blockDim.x)
+		w.c2v[i] = 0.0;
+	if (write_v2c) {
+		for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < etotal; i += (long long)gridDim.x * blockDim.x) {
+			int a = (int)(i % q);
+			long long be = i / q;
+			int e = (int)(be % g.E);
+			long long b = be / g.E;
+			// variable of edge e: binary search in voff
+			int lo = 0, hi = g.N;
+			while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (g.voff[mid] <= e) lo = mid; else hi = mid; }
+			w.v2c[i] = a ? Lin[(b * g.N + lo) * (q - 1) + (a - 1)] : 0.0;
+		}
+	}
+	for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x) {
+		w.done[i] = 0;
+		w.iters[i] = 0;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) *w.n_done = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// variable node: L_post = L_ch + c2v_0 + c2v_1 ... (in that order), decision, v2c = L_post - c2v (+ damping)
+// (NBLDPC.cpp:676-691, 718-744 | 808-823, 848-857 | 977-992, 1029-1052)
+// ---------------------------------------------------------------------------------------------------------
+template <int Q, bool DAMP>
+__global__ __launch_bounds__(256) void vn_kernel(NblGraphDev g, NblWork w, NblRun r)
+{
+	constexpr int NS = Fld<Q>::NS;
+	const int lane = lane_id();
+	const long long node = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (node >= (long long)r.B * g.N) return;
+	const int b = (int)(node / g.N), n = (int)(node % g.N);
+	if (!r.fixed_iters && w.done[b]) return;
+
+	const int e0 = g.voff[n], dv = g.voff[n + 1] - e0;
+	const double *L = w.Lch + ((size_t)b * g.N + n) * Q;
+	const double *C = w.c2v + (size_t)b * g.E * Q;
+	double *V = w.v2c + ((size_t)b * g.E + e0) * Q;
+
+	double post[NS];
+#pragma unroll
+	for (int i = 0; i < NS; i++) {
+		int a = lane + 64 * i;
+		post[i] = (a < Q) ? L[a] : 0.0;
+	}
+	for (int d = 0; d < dv; d++) {
+		const double *Cd = C + (size_t)g.v_cpos[e0 + d] * Q;
+#pragma unroll
+		for (int i = 0; i < NS; i++) {
+			int a = lane + 64 * i;
+			if (a < Q) post[i] = post[i] + Cd[a];
+		}
+	}
+	int dec = wave_decide<NS>(post, lane, Q);
+	if (lane == 0) w.dec[(size_t)b * g.N + n] = dec;
+	if (w.post) {
+		double *P = w.post + ((size_t)b * g.N + n) * Q;
+#pragma unroll
+		for (int i = 0; i < NS; i++) {
+			int a = lane + 64 * i;
+			if (a < Q) P[a] = post[i];
+		}
+	}
+	for (int d = 0; d < dv; d++) {
+		const double *Cd = C + (size_t)g.v_cpos[e0 + d] * Q;
+		double *Vd = V + (size_t)d * Q;
+		double nv[NS];
+#pragma unroll
+		for (int i = 0; i < NS; i++) {
+			int a = lane + 64 * i;
+			nv[i] = (a < Q) ? post[i] - Cd[a] : 0.0;
+		}
+		if (DAMP) {
+			double ov[NS];
+#pragma unroll
+			for (int i = 0; i < NS; i++) {
+				int a = lane + 64 * i;
+				ov[i] = (a < Q) ? Vd[a] : 0.0;
+			}
+			int before = wave_decide<NS>(ov, lane, Q);
+			int after = wave_decide<NS>(nv, lane, Q);
+			if (before != after) {
+#pragma unroll
+				for (int i = 0; i < NS; i++) nv[i] = __dadd_rn(__dmul_rn(r.damp_old, ov[i]), __dmul_rn(r.damp_new, nv[i]));
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < NS; i++) {
+			int a = lane + 64 * i;
+			if (a < Q) Vd[a] = (a == 0) ? 0.0 : nv[i];
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// syndrome + output freeze: one wave per codeword, lanes over checks (NBLDPC.cpp:693-715 / 826-846 / 999-1026)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void syn_kernel(NblGraphDev g, NblWork w, NblRun r)
+{
+	const int lane = lane_id();
+	const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (b >= r.B) return;
+	const int frozen = w.done[b];
+	if (frozen) return;
+	const int *dec = w.dec + (size_t)b * g.N;
+	int bad = 0;
+	for (int m = lane; m < g.M; m += 64) {
+		int s = 0;
+		for (int ce = g.coff[m]; ce < g.coff[m + 1]; ce++) s ^= g.mul[g.c_h[ce] * g.q + dec[g.c_var[ce]]];
+		bad |= (s != 0);
+	}
+	const int ok = (__ballot(bad) == 0ull);
+	int *out = w.out + (size_t)b * g.N;
+	for (int n = lane; n < g.N; n += 64) out[n] = dec[n];
+	if (lane == 0) {
+		if (ok) {
+			w.done[b] = 1;
+			w.iters[b] = r.iter;
+			atomicAdd(w.n_done, 1);
+		} else {
+			w.iters[b] = r.iter;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// EMS check node (NBLDPC.cpp:859-917 with SortLLRVector :1715-1746 and ConstructConf :1748-1786)
+//
+// The reference enumerates conf(q,1) U conf(nm,nc) by recursion for every output edge.  Here the same maximum
+// over the same configuration set is computed by max-plus dynamic programming over the other edges in index
+// order, so every candidate value is the same left-to-right sum ((x1+x2)+x3).. (x -> fl(x+c) is monotone, so
+// max and the rounded add commute).  What is NOT reproduced is the reference's running add-then-subtract
+// residue.
+// ---------------------------------------------------------------------------------------------------------
+
+// Top-nm selection under SortLLRVector's order: value descending, among equal values the HIGHER symbol first.
+// Wave-level quickselect on ballots: candidate sets live in scalar registers.  Returns member masks per slot and
+// the rank-0 element (value + symbol).
+template <int NS>
+__device__ __forceinline__ void select_top(const double (&v)[NS], int lane, int q, int nm, uint64_t (&member)[NS],
+                                           double &top_v, int &top_a)
+{
+	uint64_t valid[NS], cand[NS];
+#pragma unroll
+	for (int i = 0; i < NS; i++) {
+		valid[i] = __ballot(lane + 64 * i < q);
+		cand[i] = valid[i];
+		member[i] = valid[i];
+	}
+	if (nm < q) {
+		for (int guard = 0; guard < 4 * 64 + 8; guard++) {
+			// pivot: first remaining candidate
+			double pv = 0.0;
+			int pa = 0;
+			bool found = false;
+#pragma unroll
+			for (int i = 0; i < NS; i++) {
+				if (!found && cand[i]) {
+					int pl = __builtin_ctzll(cand[i]);
+					pv = read_lane_f64(v[i], pl);
+					pa = pl + 64 * i;
+					found = true;
+				}
+			}
+			if (!found) break; // cannot happen: the nm-th element is always a candidate
+			uint64_t gt[NS];
+			int G = 1;
+#pragma unroll
+			for (int i = 0; i < NS; i++) {
+				int a = lane + 64 * i;
+				gt[i] = __ballot(a < q && (v[i] > pv || (v[i] == pv && a > pa)));
+				G += __popcll(gt[i]);
+			}
+			const int ps = pa >> 6;
+			const uint64_t pbit = 1ull << (pa & 63);
+			if (G == nm) {
+#pragma unroll
+				for (int i = 0; i < NS; i++) member[i] = gt[i] | ((i == ps) ? pbit : 0ull);
+				break;
+			}
+			if (G > nm) {
+#pragma unroll
+				for (int i = 0; i < NS; i++) cand[i] &= gt[i];
+			} else {
+#pragma unroll
+				for (int i = 0; i < NS; i++) cand[i] &= ~gt[i] & ~((i == ps) ? pbit : 0ull);
+			}
+		}
+	}
+	// rank 0: maximum under the same order
+	double bv = -__builtin_huge_val();
+	int ba = -1;
+#pragma unroll
+	for (int i = 0; i < NS; i++) {
+		int a = lane + 64 * i;
+		if (a < q && (v[i] > bv || (v[i] == bv && a > ba))) { bv = v[i]; ba = a; }
+	}
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) {
+		double ob = __shfl_xor(bv, off, 64);
+		int oa = __shfl_xor(ba, off, 64);
+		if (ob > bv || (ob == bv && oa > ba)) { bv = ob; ba = oa; }
+	}
+	top_v = uniform_f64(bv);
+	top_a = uniform(ba);
+}
+
+struct EmsLds {
+	double *U;   // [dc][Q]   check-domain input vectors: U[j][h_j*a] = v2c_j[a], U[j][0] = 0
+	double *lv;  // [dc][nm]  values of the nm most reliable entries (rank 0 first)
+	int *lt;     // [dc][nm]  their check-domain symbols
+	double *A;   // [layers][Q] DP ping
+	double *Bq;  // [layers][Q] DP pong
+	double *Sv;  // [Q]       final configuration-set maxima of the current output edge
+};
+
+template <int Q>
+__global__ __launch_bounds__(64) void cn_ems_kernel(NblGraphDev g, NblWork w, NblRun r, int layers)
+{
+	constexpr int NS = Fld<Q>::NS;
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const int lane = lane_id();
+	const int b = blockIdx.x / g.M, m = blockIdx.x % g.M;
+	if (!r.fixed_iters && w.done[b]) return;
+	const int c0 = g.coff[m], dc = g.coff[m + 1] - c0;
+	const int nm = r.nm, nc = r.nc;
+
+	EmsLds s;
+	s.U = (double *)smem;
+	s.A = s.U + g.maxdc * Q;
+	s.Bq = s.A + layers * Q;
+	s.Sv = s.Bq + layers * Q;
+	s.lv = s.Sv + Q;
+	s.lt = (int *)(s.lv + g.maxdc * nm);
+
+	const double *V = w.v2c + (size_t)b * g.E * Q;
+	double *C = w.c2v + ((size_t)b * g.E + c0) * Q;
+
+	// ---- stage the dc incoming vectors: permute into the check domain, select the nm best -----------------
+	for (int j = 0; j < dc; j++) {
+		const double *Vj = V + (size_t)g.c_epos[c0 + j] * Q;
+		GfMul<Q> mh;
+		mh.init(g.c_h[c0 + j], g.poly, lane);
+		double v[NS];
+		int t[NS];
+#pragma unroll
+		for (int i = 0; i < NS; i++) {
+			int a = lane + 64 * i;
+			v[i] = (a < Q && a > 0) ? Vj[a] : 0.0;
+			t[i] = mh.at_slot(i);
+			if (a < Q) s.U[j * Q + t[i]] = v[i];
+		}
+		uint64_t member[NS];
+		double top_v;
+		int top_a;
+		select_top<NS>(v, lane, Q, nm, member, top_v, top_a);
+		// compact the members into the list, rank 0 swapped to the front
+		int base = 0, p0 = 0;
+#pragma unroll
+		for (int i = 0; i < NS; i++) {
+			if (i == (top_a >> 6)) p0 = base + __popcll(member[i] & ((1ull << (top_a & 63)) - 1ull));
+			base += __popcll(member[i]);
+		}
+		base = 0;
+#pragma unroll
+		for (int i = 0; i < NS; i++) {
+			int a = lane + 64 * i;
+			if ((member[i] >> lane) & 1ull) {
+				int pos = base + prefix_count(member[i]);
+				if (a == top_a) pos = 0;
+				else if (pos == 0) pos = p0;
+				s.lv[j * nm + pos] = v[i];
+				s.lt[j * nm + pos] = t[i];
+			}
+			base += __popcll(member[i]);
+		}
+	}
+	__syncthreads();
+
+	// ---- one output edge at a time ---------------------------------------------------------------------------
+	for (int x = 0; x < dc; x++) {
+		// the other edges in index order: OTH(l) = l-th edge != x
+#define OTH(l) ((l) + ((l) >= x ? 1 : 0))
+		const int rn = dc - 1;
+		int zall = 0;
+		for (int l = 0; l < rn; l++) zall ^= s.lt[OTH(l) * nm];
+
+		double S[NS];
+#pragma unroll
+		for (int i = 0; i < NS; i++) S[i] = -NBL_DBL_MAX;
+
+		// conf(q,1): at most one edge deviates, to ANY symbol (:894)
+		for (int pi = 0; pi < rn; pi++) {
+			const int jd = OTH(pi);
+			const int shift = zall ^ s.lt[jd * nm];
+#pragma unroll
+			for (int i = 0; i < NS; i++) {
+				int sym = lane + 64 * i;
+				if (sym < Q) {
+					double u = s.U[jd * Q + (sym ^ shift)];
+					double acc = 0.0;
+					for (int l = 0; l < rn; l++) acc = acc + ((l == pi) ? u : s.lv[OTH(l) * nm]);
+					S[i] = dmax(S[i], acc);
+				}
+			}
+		}
+
+		// conf(nm,nc): at most nc edges deviate, each inside its nm best (:897)
+		if (layers == 1) {
+			// nc >= dc-1: no deviation counting needed -> plain truncated max-plus convolution
+			double *A = s.A, *Bq = s.Bq;
+			__syncthreads();
+			for (int sidx = lane; sidx < Q; sidx += 64) A[sidx] = NBL_NEG_INF;
+			__syncthreads();
+			if (rn == 1) {
+				const int j1 = OTH(0);
+				for (int k = lane; k < nm; k += 64) A[s.lt[j1 * nm + k]] = 0.0 + s.lv[j1 * nm + k];
+			} else {
+				const int j1 = OTH(0), j2 = OTH(1);
+				for (int idx = lane; idx < nm * nm; idx += 64) {
+					int k1 = idx / nm, k2 = idx - k1 * nm;
+					double val = (0.0 + s.lv[j1 * nm + k1]) + s.lv[j2 * nm + k2];
+					__hip_atomic_fetch_max(&A[s.lt[j1 * nm + k1] ^ s.lt[j2 * nm + k2]], val, __ATOMIC_RELAXED,
+					                       __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			}
+			__syncthreads();
+			for (int l = 2; l < rn; l++) {
+				const int jl = OTH(l);
+				double acc[NS];
+#pragma unroll
+				for (int i = 0; i < NS; i++) acc[i] = NBL_NEG_INF;
+				for (int k = 0; k < nm; k++) {
+					const int tk = uniform(s.lt[jl * nm + k]);
+					const double vk = s.lv[jl * nm + k];
+#pragma unroll
+					for (int i = 0; i < NS; i++) {
+						int sym = lane + 64 * i;
+						if (sym < Q) acc[i] = dmax(acc[i], A[sym ^ tk] + vk);
+					}
+				}
+				if (l == rn - 1) {
+#pragma unroll
+					for (int i = 0; i < NS; i++) S[i] = dmax(S[i], acc[i]);
+				} else {
+#pragma unroll
+					for (int i = 0; i < NS; i++) {
+						int sym = lane + 64 * i;
+						if (sym < Q) Bq[sym] = acc[i];
+					}
+					__syncthreads();
+					double *T = A; A = Bq; Bq = T;
+				}
+			}
+			if (rn <= 2) {
+#pragma unroll
+				for (int i = 0; i < NS; i++) {
+					int sym = lane + 64 * i;
+					if (sym < Q) S[i] = dmax(S[i], A[sym]);
+				}
+			}
+		} else {
+			// layered DP: A[d][s] = best value reaching check sum s with exactly d deviations
+			double *A = s.A, *Bq = s.Bq;
+			__syncthreads();
+			for (int idx = lane; idx < layers * Q; idx += 64) A[idx] = (idx == 0) ? 0.0 : NBL_NEG_INF;
+			__syncthreads();
+			for (int l = 0; l < rn; l++) {
+				const int jl = OTH(l);
+				const int z = s.lt[jl * nm];
+				const double mz = s.lv[jl * nm];
+				for (int d = 0; d < layers; d++) {
+					double acc[NS];
+#pragma unroll
+					for (int i = 0; i < NS; i++) {
+						int sym = lane + 64 * i;
+						acc[i] = (sym < Q) ? A[d * Q + (sym ^ z)] + mz : NBL_NEG_INF;
+					}
+					if (d >= 1) {
+						for (int k = 1; k < nm; k++) {
+							const int tk = uniform(s.lt[jl * nm + k]);
+							const double vk = s.lv[jl * nm + k];
+#pragma unroll
+							for (int i = 0; i < NS; i++) {
+								int sym = lane + 64 * i;
+								if (sym < Q) acc[i] = dmax(acc[i], A[(d - 1) * Q + (sym ^ tk)] + vk);
+							}
+						}
+					}
+#pragma unroll
+					for (int i = 0; i < NS; i++) {
+						int sym = lane + 64 * i;
+						if (sym < Q) Bq[d * Q + sym] = acc[i];
+					}
+				}
+				__syncthreads();
+				double *T = A; A = Bq; Bq = T;
+			}
+			for (int d = 0; d < layers; d++) {
+#pragma unroll
+				for (int i = 0; i < NS; i++) {
+					int sym = lane + 64 * i;
+					if (sym < Q) S[i] = dmax(S[i], A[d * Q + sym]);
+				}
+			}
+		}
+
+		// ---- output: c2v[a] = shape(S[h_x a] - S[0]) (:899-916) ----------------------------------------------
+		double *Sv = s.Sv;
+#pragma unroll
+		for (int i = 0; i < NS; i++) {
+			int sym = lane + 64 * i;
+			if (sym < Q) Sv[sym] = S[i];
+		}
+		__syncthreads();
+		{
+			GfMul<Q> mh;
+			mh.init(g.c_h[c0 + x], g.poly, lane);
+			const double s0 = Sv[0];
+			double *Cx = C + (size_t)x * Q;
+#pragma unroll
+			for (int i = 0; i < NS; i++) {
+				int a = lane + 64 * i;
+				if (a < Q) Cx[a] = (a == 0) ? 0.0 : shape_llr(Sv[mh.at_slot(i)] - s0, r.factor, r.offset);
+			}
+		}
+#undef OTH
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// state read-back (parity tests): padded device layout -> [.][q-1]
+// ---------------------------------------------------------------------------------------------------------
+__global__ void unpad_kernel(const double *__restrict__ src, double *__restrict__ dst, const int *__restrict__ map,
+                             int rows, int q)
+{
+	long long total = (long long)rows * (q - 1);
+	for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+		int a = (int)(i % (q - 1)) + 1;
+		int row = (int)(i / (q - 1));
+		int srow = map ? map[row] : row;
+		dst[i] = src[(size_t)srow * q + a];
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------------------
+#define NBL_DISPATCH_Q(q, ...)                                  \
+	switch (q) {                                                \
+	case 4: { constexpr int QQ = 4; __VA_ARGS__; } break;       \
+	case 8: { constexpr int QQ = 8; __VA_ARGS__; } break;       \
+	case 16: { constexpr int QQ = 16; __VA_ARGS__; } break;     \
+	case 32: { constexpr int QQ = 32; __VA_ARGS__; } break;     \
+	case 64: { constexpr int QQ = 64; __VA_ARGS__; } break;     \
+	case 128: { constexpr int QQ = 128; __VA_ARGS__; } break;   \
+	case 256: { constexpr int QQ = 256; __VA_ARGS__; } break;   \
+	default: return hipErrorInvalidValue;                       \
+	}
+
+hipError_t nbl_launch_init(const double *d_Lin, const NblGraphDev &g, const NblWork &w, int B, int write_v2c, hipStream_t st)
+{
+	long long total = (long long)B * g.E * g.q;
+	int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+	if (blocks < 1) blocks = 1;
+	hipLaunchKernelGGL(init_kernel, dim3(blocks), dim3(256), 0, st, d_Lin, g, w, B, write_v2c);
+	return hipGetLastError();
+}
+
+hipError_t nbl_launch_vn(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool damp, hipStream_t st)
+{
+	long long nodes = (long long)r.B * g.N;
+	dim3 grid((unsigned)((nodes + 3) / 4)), block(256);
+	if (damp) { NBL_DISPATCH_Q(g.q, vn_kernel<QQ, true><<<grid, block, 0, st>>>(g, w, r)) }
+	else { NBL_DISPATCH_Q(g.q, vn_kernel<QQ, false><<<grid, block, 0, st>>>(g, w, r)) }
+	return hipGetLastError();
+}
+
+hipError_t nbl_launch_syn(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
+{
+	dim3 grid((unsigned)((r.B + 3) / 4)), block(256);
+	hipLaunchKernelGGL(syn_kernel, grid, block, 0, st, g, w, r);
+	return hipGetLastError();
+}
+
+size_t nbl_ems_lds_bytes(const NblGraphDev &g, int nm, int layers)
+{
+	size_t doubles = (size_t)g.maxdc * g.q + (2 * (size_t)layers + 1) * g.q + (size_t)g.maxdc * nm;
+	return doubles * 8 + (size_t)g.maxdc * nm * 4 + 16;
+}
+
+int nbl_ems_layers(const NblGraphDev &g, int nc)
+{
+	return (nc >= g.maxdc - 1) ? 1 : nc + 1;
+}
+
+hipError_t nbl_launch_cn_ems(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
+{
+	const int layers = nbl_ems_layers(g, r.nc);
+	const size_t lds = nbl_ems_lds_bytes(g, r.nm, layers);
+	dim3 grid((unsigned)((long long)r.B * g.M)), block(64);
+	NBL_DISPATCH_Q(g.q, cn_ems_kernel<QQ><<<grid, block, lds, st>>>(g, w, r, layers))
+	return hipGetLastError();
+}
+
+hipError_t nbl_launch_unpad(const double *src, double *dst, const int *map, int rows, int q, hipStream_t st)
+{
+	long long total = (long long)rows * (q - 1);
+	int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+	if (blocks < 1) blocks = 1;
+	hipLaunchKernelGGL(unpad_kernel, dim3(blocks), dim3(256), 0, st, src, dst, map, rows, q);
+	return hipGetLastError();
+}
