@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the NB-LDPC decode hot path on MI355X.
+
+Metric (BASELINE.json): decoded codewords/sec @ 50 iterations, GF(256) 512.256 rate-1/2 code, EMS nm=32, plus the
+achieved fraction of the HBM roofline.  A "step" is one pass of the decoder (50 fixed iterations) over one batch
+of codewords whose channel LLRs already sit in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: every rank
+decodes its own batch (independent frames, no data-path collective: SURVEY 8e), scaling is weak.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      dominant kernel (EMS check node): algorithmic bytes per launch / mean launch time (HIP events on
+                the launch stream inside the timed region) against the 8 TB/s HBM peak
+  cpu_baseline  the oracle's literal restatement of the reference algorithm, timed on this host's cores on a
+                bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+CODE = "divsalar.UNBLDPC.512.256.GF.256"
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synth_llr(torch, code_q, N, B, ebn0_db, seed, device):
+    """Channel LLRs of the all-zero codeword over BPSK/AWGN in the reference's symbol-LLR convention
+    (Comm.cpp:157-178 sigma, :328-337 noise, :340-380 bit -> symbol LLR): L[a-1] = sum of bit LLRs over set bits of a."""
+    p = code_q.bit_length() - 1
+    rate = 0.5
+    sigma = 1.0 / np.sqrt(2 * 1 * rate * 10 ** (ebn0_db / 10.0))
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    rx = 1.0 + sigma * torch.randn((B, N, p), dtype=torch.float64, device=device, generator=gen)  # BPSK point 0 -> +1
+    bit_llr = -2.0 * rx / (sigma * sigma)
+    a = torch.arange(1, code_q, device=device)
+    mask = ((a[:, None] >> torch.arange(p, device=device)[None, :]) & 1).to(torch.float64)  # [q-1][p]
+    return torch.matmul(bit_llr, mask.t()).contiguous()  # [B][N][q-1]
+
+
+def cpu_baseline(nb, L_host, nm, nc, max_iter, threads):
+    import pyoracle as po
+    po.build()
+    N, M, q, ev, ec, eh = nb.datafiles.code_edges(CODE)
+    code = po.Code(edges=(N, M, q, ev, ec, eh))
+    gf = po.GF(q)
+    mk = lambda: po.Decoder(code, gf, po.EMS, max_iter, po.LITERAL, ems_nm=nm, ems_nc=nc, fixed_iters=1)  # noqa: E731
+    t0 = time.time()
+    po.decode_batch(mk, L_host, nthreads=threads)
+    dt = time.time() - t0
+    return L_host.shape[0] / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16384, help="codewords per GPU per step")
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--nm", type=int, default=32)
+    ap.add_argument("--nc", type=int, default=3)
+    ap.add_argument("--ebn0", type=float, default=1.0)
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="codewords for the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import nbldpc_amd as nb
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    code = nb.Code(CODE)
+    B = args.batch
+    dec = nb.Decoder(code, nb.METHOD_EMS, args.iters, ems_nm=args.nm, ems_nc=args.nc, fixed_iters=1, max_batch=B, device=local_rank)
+    dec.profiling(True)
+    L = synth_llr(torch, code.q, code.N, B, args.ebn0, 173 + rank, dev)
+    out = torch.zeros((B, code.N), dtype=torch.int32, device=dev)
+    conv = torch.zeros(B, dtype=torch.uint8, device=dev)
+    its = torch.zeros(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        dec.decode_device(L.data_ptr(), B, out.data_ptr(), conv.data_ptr(), its.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms_cn = ms_vn = ms_syn = 0.0
+    n_cn = 0
+    for _ in range(args.steps):
+        step()
+        ms, launches = dec.last_timing()  # HIP events recorded on the launch stream around every kernel
+        ms_vn += ms[0]; ms_syn += ms[1]; ms_cn += ms[2]; n_cn += launches[2]
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_cw = B * args.steps * world
+    value = total_cw / dt
+    q, N, E = code.q, code.N, code.E
+    # bytes per codeword per iteration, w = 8 (FP64): L_ch read (N) + c2v read, v2c write, v2c read, c2v write (4E)
+    bytes_iter = 8 * (q - 1) * (N + 4 * E)
+    bytes_cw = 8 * (q - 1) * N + args.iters * bytes_iter + 4 * N + 4
+    # dominant kernel = EMS check node: reads E v2c vectors, writes E c2v vectors per codeword per launch
+    cn_bytes_launch = B * 8 * (q - 1) * 2 * E
+    cn_ms = ms_cn / max(n_cn, 1)
+    cn_gbs = cn_bytes_launch / (cn_ms * 1e-3) / 1e9 if cn_ms > 0 else 0.0
+    res = {
+        "metric": "decoded codewords/sec @ 50 iters, GF(256) N=512 rate-1/2",
+        "value": value, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{CODE} over BPSK/AWGN Eb/N0={args.ebn0} dB, EMS nm={args.nm} nc={args.nc}, "
+                               f"{args.iters} fixed iterations, batch {B} codewords per GPU",
+                   "batch_per_gpu": B, "iters": args.iters, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+        "algorithmic_GBps_whole_job": total_cw * bytes_cw / dt / 1e9,
+        "hbm_roofline_frac_whole_job": total_cw * bytes_cw / dt / 1e9 / (HBM_PEAK_GBS * world),
+        "converged_frac": float(conv.float().mean().item()),
+        "phase_ms_per_step": {"vn": ms_vn / args.steps, "syndrome": ms_syn / args.steps, "cn": ms_cn / args.steps},
+        "roofline": {"kernel": "cn_ems_kernel<256>", "bound": "hbm", "achieved": cn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": cn_gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": cn_bytes_launch, "ms_per_launch": cn_ms},
+    }
+    if rank == 0 and world == 1 and args.cpu_sample != 0:
+        threads = os.cpu_count() or 1
+        try:
+            threads = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        n = args.cpu_sample if args.cpu_sample > 0 else threads
+        cps, secs = cpu_baseline(nb, L[:n].cpu().numpy(), args.nm, args.nc, args.iters, threads)
+        res["cpu_baseline"] = {"value": cps, "unit": "codewords/s", "cores": threads, "kind": "port",
+                               "sample": f"{n} codewords of the same batch, {args.iters} fixed iterations, oracle literal "
+                                         f"restatement of the reference EMS (gcc -O2), {secs:.1f} s wall"}
+    if rank == 0:
+        print(json.dumps(res))
+    dec.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

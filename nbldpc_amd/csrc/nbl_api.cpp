@@ -27,8 +27,11 @@ struct nbl_decoder {
 	uint8_t *d_conv8 = nullptr;
 	hipStream_t stream = nullptr;
 	bool record_state = false;
+	bool all_dc4 = false;       // every check has degree 4
+	bool force_generic = false; // debug: always use the generic kernels
 	bool profiling = false;
 	hipEvent_t ev[2] = {nullptr, nullptr};
+	std::vector<hipEvent_t> pev; // per-launch events (profiling only)
 	double ms[4] = {0, 0, 0, 0};
 	long long launches[3] = {0, 0, 0};
 	int last_B = 0;
@@ -197,6 +200,8 @@ extern "C" nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_m
 	    (st = upload(d, c_hinv, &d->g.c_hinv)) || (st = upload(d, mul8, &d->g.mul)))
 		return fail_create(d, st, "");
 	d->d_e2c_map = (int *)d->g.v_cpos;
+	d->all_dc4 = true;
+	for (int m = 0; m < M; m++) d->all_dc4 = d->all_dc4 && (code->chk_deg[m] == 4);
 	void *cnt = nullptr;
 	if (hipMalloc(&cnt, 16) != hipSuccess) return fail_create(d, NBL_ERR_NOMEM, "hipMalloc failed");
 	d->graph_allocs.push_back(cnt);
@@ -216,6 +221,7 @@ extern "C" void nbl_destroy(nbl_decoder *d)
 	for (void *p : d->graph_allocs) (void)hipFree(p);
 	for (auto &e : d->ev)
 		if (e) (void)hipEventDestroy(e);
+	for (auto &e : d->pev) (void)hipEventDestroy(e);
 	if (d->stream) (void)hipStreamDestroy(d->stream);
 	delete d;
 }
@@ -224,6 +230,35 @@ extern "C" nbl_status nbl_set_profiling(nbl_decoder *d, int32_t on)
 {
 	if (!d) return NBL_ERR_ARG;
 	d->profiling = on != 0;
+	return NBL_OK;
+}
+
+// Diagnostic only (not part of include/nbldpc.h): route every shape through the generic kernels.
+extern "C" nbl_status nbl_debug_force_generic(nbl_decoder *d, int32_t on)
+{
+	if (!d) return NBL_ERR_ARG;
+	d->force_generic = on != 0;
+	return NBL_OK;
+}
+
+// Diagnostic only (not part of include/nbldpc.h): in-kernel cycle stamps of the check-node kernel.
+extern "C" nbl_status nbl_debug_stamps(nbl_decoder *d, int32_t on, unsigned long long out[16])
+{
+	if (!d) return NBL_ERR_ARG;
+	HIP_TRY(d, hipSetDevice(d->device));
+	if (out && d->w.stamps) {
+		HIP_TRY(d, hipStreamSynchronize(d->stream));
+		HIP_TRY(d, hipDeviceSynchronize());
+		HIP_TRY(d, hipMemcpy(out, d->w.stamps, 16 * 8, hipMemcpyDeviceToHost));
+	}
+	if (on && !d->w.stamps) {
+		void *p = nullptr;
+		HIP_TRY(d, hipMalloc(&p, 16 * 8));
+		d->graph_allocs.push_back(p);
+		d->w.stamps = (unsigned long long *)p;
+	}
+	if (d->w.stamps && on) HIP_TRY(d, hipMemset(d->w.stamps, 0, 16 * 8));
+	if (!on) d->w.stamps = nullptr;
 	return NBL_OK;
 }
 
@@ -245,7 +280,10 @@ extern "C" nbl_status nbl_last_timing(nbl_decoder *d, double ms[4], int64_t laun
 static nbl_status launch_cn(nbl_decoder *d, const NblRun &r, hipStream_t st)
 {
 	switch (d->prm.method) {
-	case NBL_METHOD_EMS: HIP_TRY(d, nbl_launch_cn_ems(d->g, d->w, r, st)); break;
+	case NBL_METHOD_EMS:
+		if (!d->force_generic && nbl_ems256_applicable(d->g, d->all_dc4, r.nm, r.nc)) HIP_TRY(d, nbl_launch_cn_ems256(d->g, d->w, r, st));
+		else HIP_TRY(d, nbl_launch_cn_ems(d->g, d->w, r, st));
+		break;
 	default: d->err = "check-node kernel for this method is not built yet"; return NBL_ERR_UNSUPPORTED;
 	}
 	return NBL_OK;
@@ -264,12 +302,24 @@ static nbl_status run_iterations(nbl_decoder *d, const double *d_Lin, int B, hip
 	r.damp_old = (p.method == NBL_METHOD_BP) ? 0.5 : 0.25;  // NBLDPC.cpp:739 / :1046
 	r.damp_new = (p.method == NBL_METHOD_BP) ? 0.5 : 0.75;
 	d->launches[0] = d->launches[1] = d->launches[2] = 0;
-	if (d->profiling) HIP_TRY(d, hipEventRecord(d->ev[0], st));
+	// profiling: one event after every launch on the launch stream; phase time = sum of the gaps it closes
+	size_t nev = 0;
+	std::vector<int> tag; // 0 vn, 1 syn, 2 cn, 3 other
+	auto mark = [&](int t) -> hipError_t {
+		if (!d->profiling) return hipSuccess;
+		if (nev == d->pev.size()) { hipEvent_t e; hipError_t rc = hipEventCreate(&e); if (rc != hipSuccess) return rc; d->pev.push_back(e); }
+		tag.push_back(t);
+		return hipEventRecord(d->pev[nev++], st);
+	};
+	HIP_TRY(d, mark(3));
 	HIP_TRY(d, nbl_launch_init(d_Lin, d->g, d->w, B, damp ? 1 : 0, st));
+	HIP_TRY(d, mark(3));
 	for (int it = 1; it <= p.max_iter; it++) {
 		r.iter = it;
 		HIP_TRY(d, nbl_launch_vn(d->g, d->w, r, damp, st));
+		HIP_TRY(d, mark(0));
 		HIP_TRY(d, nbl_launch_syn(d->g, d->w, r, st));
+		HIP_TRY(d, mark(1));
 		d->launches[0]++; d->launches[1]++;
 		if (!p.fixed_iters && p.poll_every > 0 && (it % p.poll_every) == 0) {
 			int n_done = 0;
@@ -279,14 +329,18 @@ static nbl_status run_iterations(nbl_decoder *d, const double *d_Lin, int B, hip
 		}
 		nbl_status s = launch_cn(d, r, st);
 		if (s) return s;
+		HIP_TRY(d, mark(2));
 		d->launches[2]++;
 	}
 	if (d->profiling) {
-		HIP_TRY(d, hipEventRecord(d->ev[1], st));
-		HIP_TRY(d, hipEventSynchronize(d->ev[1]));
-		float ms = 0;
-		HIP_TRY(d, hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
-		d->ms[3] = ms;
+		HIP_TRY(d, hipEventSynchronize(d->pev[nev - 1]));
+		d->ms[0] = d->ms[1] = d->ms[2] = d->ms[3] = 0;
+		for (size_t i = 1; i < nev; i++) {
+			float ms = 0;
+			HIP_TRY(d, hipEventElapsedTime(&ms, d->pev[i - 1], d->pev[i]));
+			if (tag[i] < 3) d->ms[tag[i]] += ms;
+			d->ms[3] += ms;
+		}
 	}
 	d->last_B = B;
 	return NBL_OK;

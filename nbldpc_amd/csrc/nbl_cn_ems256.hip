@@ -1,0 +1,421 @@
+// nbldpc_amd/csrc/nbl_cn_ems256.hip -- EMS check node specialised for the headline shape:
+//   GF(256), every check of degree 4, nc >= 3 (no deviation counting), nm in {8,16,32,64}.
+// (BASELINE configs 2 and 3: divsalar.UNBLDPC.{128.64,512.256}.GF.256, EMS nm=16/32.)
+//
+// Same arithmetic as cn_ems_kernel<256> (nbl_kernels.hip) -- the generic kernel is the readable statement of the
+// algorithm and serves every other shape; tests check both against the oracle.  What differs is the mapping:
+//   * lane l owns symbols {2l, 2l+1, 128+2l, 129+2l}: a q-vector is two 16-byte loads/stores per lane, and a
+//     max-plus XOR-gather "P[s ^ t]" is two conflict-free ds_read_b128 (natural layout, lane XOR only permutes the
+//     16-byte slots inside one 256-byte LDS row).
+//   * the four conf(q,1) result vectors stay in registers; one 2 KB LDS buffer per role (U, P, S) -> 9.5 KB per
+//     wave at nm = 32, four waves per SIMD.
+//   * the nm-best lists are packed {value, symbol} 16-byte entries, split by bit 0 of the symbol so the pair swap
+//     of the gather is resolved by loop structure instead of per-element selects.
+//   * top-nm selection: ballot quickselect with candidate sets in scalar registers, two edges interleaved.
+#include <hip/hip_runtime.h>
+#include "nbl_device.h"
+#include "nbl_kernels.h"
+
+namespace {
+
+constexpr int Q = 256;
+
+struct __attribute__((aligned(16))) ListEnt { double v; int t; int pad; };
+
+// ---- 64-bit wave max through DPP moves (no LDS) ------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_mov_f64(double x)
+{
+	int lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), CTRL, ROW_MASK, 0xF, false);
+	int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), CTRL, ROW_MASK, 0xF, false);
+	return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_max_f64(double x)
+{
+	x = dmax(x, dpp_mov_f64<0xB1>(x));        // quad_perm [1,0,3,2]
+	x = dmax(x, dpp_mov_f64<0x4E>(x));        // quad_perm [2,3,0,1]
+	x = dmax(x, dpp_mov_f64<0x141>(x));       // row_half_mirror
+	x = dmax(x, dpp_mov_f64<0x140>(x));       // row_mirror
+	x = dmax(x, dpp_mov_f64<0x142, 0xA>(x));  // row_bcast15 into rows 1,3
+	x = dmax(x, dpp_mov_f64<0x143, 0xC>(x));  // row_bcast31 into rows 2,3
+	return read_lane_f64(x, 63);
+}
+
+// symbol of slot i of lane l in this kernel's layout
+__device__ __forceinline__ int sym_of(int lane, int i) { return 2 * lane + (i & 1) + 128 * (i >> 1); }
+
+// highest symbol among the set bits of four slot masks (-1 if empty)
+__device__ __forceinline__ int highest_sym(const uint64_t (&m)[4])
+{
+	int best = -1;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		if (m[i]) {
+			int l = 63 - __builtin_clzll(m[i]);
+			int a = 2 * l + (i & 1) + 128 * (i >> 1);
+			best = a > best ? a : best;
+		}
+	}
+	return best;
+}
+
+// h * a for this layout: lane bits 0..5 are symbol bits 1..6, slot bit 0 is symbol bit 0, slot bit 1 is symbol bit 7
+struct GfMulL {
+	int b0, b7, lane_part;
+	__device__ __forceinline__ void init(int h, int poly, int lane)
+	{
+		int x = h;
+		b0 = x;
+		lane_part = 0;
+#pragma unroll
+		for (int i = 1; i < 8; i++) {
+			x <<= 1;
+			if (x & Q) x ^= poly;
+			if (i < 7) lane_part ^= (-((lane >> (i - 1)) & 1)) & x;
+			else b7 = x;
+		}
+	}
+	__device__ __forceinline__ int at_slot(int i) const { return lane_part ^ ((i & 1) ? b0 : 0) ^ ((i & 2) ? b7 : 0); }
+	__device__ __forceinline__ int scalar(int a, int h, int poly) const
+	{
+		int x = h, acc = 0;
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			if ((a >> i) & 1) acc ^= x;
+			x <<= 1;
+			if (x & Q) x ^= poly;
+		}
+		return acc;
+	}
+};
+
+struct SelState {
+	uint64_t cand[4];
+	uint64_t gt[4], eq[4];
+	int done;
+};
+
+// one quickselect step for one edge; everything except the compares is scalar
+__device__ __forceinline__ void select_step(const double (&v)[4], int nm, SelState &s)
+{
+	if (s.done) return;
+	const uint64_t any = s.cand[0] | s.cand[1] | s.cand[2] | s.cand[3];
+	if (!any) { s.done = 1; return; } // only reachable with NaN inputs
+	// every lane offers its first remaining candidate; the pivot is the offer of the first lane that has one
+	double offer = (s.cand[0] >> lane_id()) & 1 ? v[0] : (s.cand[1] >> lane_id()) & 1 ? v[1] : (s.cand[2] >> lane_id()) & 1 ? v[2] : v[3];
+	const double pv = read_lane_f64(offer, __builtin_ctzll(any));
+	uint64_t gt[4], ge[4];
+	int cgt = 0, cge = 0;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		gt[i] = __ballot(v[i] > pv);
+		ge[i] = __ballot(v[i] >= pv);
+		cgt += __popcll(gt[i]);
+		cge += __popcll(ge[i]);
+	}
+	if (cgt >= nm) {
+#pragma unroll
+		for (int i = 0; i < 4; i++) s.cand[i] &= gt[i];
+	} else if (cge >= nm) {
+#pragma unroll
+		for (int i = 0; i < 4; i++) { s.gt[i] = gt[i]; s.eq[i] = ge[i] & ~gt[i]; }
+		s.done = 1;
+	} else {
+#pragma unroll
+		for (int i = 0; i < 4; i++) s.cand[i] &= ~ge[i];
+	}
+}
+
+// members of the nm best under SortLLRVector's order (value desc, higher symbol first among equals)
+__device__ __forceinline__ void finish_members(SelState &s, int nm, uint64_t (&member)[4])
+{
+	int cgt = 0, ceq = 0;
+#pragma unroll
+	for (int i = 0; i < 4; i++) { cgt += __popcll(s.gt[i]); ceq += __popcll(s.eq[i]); }
+	int need = nm - cgt;
+#pragma unroll
+	for (int i = 0; i < 4; i++) member[i] = s.gt[i];
+	if (need == ceq) {
+#pragma unroll
+		for (int i = 0; i < 4; i++) member[i] |= s.eq[i];
+	} else {
+		// ties straddle the cut: take the highest symbols of the tie group (rare)
+		uint64_t eq[4] = {s.eq[0], s.eq[1], s.eq[2], s.eq[3]};
+		for (; need > 0; need--) {
+			int a = highest_sym(eq);
+			int i = ((a >> 7) << 1) | (a & 1), l = (a & 127) >> 1;
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				if (k == i) { member[k] |= 1ull << l; eq[k] &= ~(1ull << l); }
+		}
+	}
+}
+
+} // namespace
+
+__global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r, int lognm)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const int lane = lane_id();
+	const int b = blockIdx.x / g.M, m = blockIdx.x % g.M;
+	if (!r.fixed_iters && w.done[b]) return;
+	const int c0 = g.coff[m];
+	const int nm = r.nm;
+
+	double *U = (double *)smem;          // [256] check-domain copy of one input vector
+	double *P = U + Q;                   // [256] pair convolution
+	double *Sx = P + Q;                  // [256] final maxima of one output edge
+	ListEnt *lst = (ListEnt *)(Sx + Q);  // [4][nm]
+
+	unsigned long long st_t0 = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	const bool st_on = (w.stamps != nullptr) && ((blockIdx.x & 63) == 0);
+#define STAMP(i) do { if (st_on) { unsigned long long t1_ = clock64(); st_acc[i] += t1_ - st_t0; st_t0 = t1_; } } while (0)
+	if (st_on) st_t0 = clock64();
+
+	const double *V = w.v2c + (size_t)b * g.E * Q;
+	double *C = w.c2v + ((size_t)b * g.E + c0) * Q;
+
+	// ---- load the four incoming vectors (two 16-byte loads each) and their check-domain symbols ------------------
+	double v[4][4];
+	int t[4][4];
+	int hcoef[4];
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		const double2 *src = (const double2 *)(V + (size_t)g.c_epos[c0 + j] * Q);
+		double2 d0 = src[lane], d1 = src[64 + lane];
+		v[j][0] = (lane == 0) ? 0.0 : d0.x;
+		v[j][1] = d0.y;
+		v[j][2] = d1.x;
+		v[j][3] = d1.y;
+		hcoef[j] = g.c_h[c0 + j];
+	}
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		GfMulL mh;
+		mh.init(hcoef[j], g.poly, lane);
+#pragma unroll
+		for (int i = 0; i < 4; i++) t[j][i] = mh.at_slot(i);
+	}
+	STAMP(0);
+
+	// ---- rank 0 of every edge: value m_j, check-domain symbol z_j ---------------------------------------------------
+	double mtop[4];
+	int ztop[4];
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		double loc = dmax(dmax(v[j][0], v[j][1]), dmax(v[j][2], v[j][3]));
+		mtop[j] = wave_max_f64(loc);
+		uint64_t eq[4];
+#pragma unroll
+		for (int i = 0; i < 4; i++) eq[i] = __ballot(v[j][i] == mtop[j]);
+		int a = highest_sym(eq);
+		GfMulL mh;
+		ztop[j] = mh.scalar(a, hcoef[j], g.poly);
+	}
+	STAMP(1);
+
+	// ---- top-nm selection, two edges interleaved -------------------------------------------------------------------
+	uint64_t member[4][4];
+#pragma unroll
+	for (int jp = 0; jp < 4; jp += 2) {
+		SelState s0, s1;
+#pragma unroll
+		for (int i = 0; i < 4; i++) { s0.cand[i] = ~0ull; s1.cand[i] = ~0ull; s0.gt[i] = s0.eq[i] = s1.gt[i] = s1.eq[i] = 0; }
+		s0.done = s1.done = 0;
+		for (int guard = 0; guard < 300 && !(s0.done && s1.done); guard++) {
+			select_step(v[jp], nm, s0);
+			select_step(v[jp + 1], nm, s1);
+		}
+		finish_members(s0, nm, member[jp]);
+		finish_members(s1, nm, member[jp + 1]);
+	}
+	STAMP(2);
+
+	// ---- compact members into packed lists, entries with symbol bit 0 clear first ---------------------------------
+	int n0[4];
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		uint64_t g0[4], g1[4];
+		int c0n = 0;
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			uint64_t even = __ballot((t[j][i] & 1) == 0);
+			g0[i] = member[j][i] & even;
+			g1[i] = member[j][i] & ~even;
+			c0n += __popcll(g0[i]);
+		}
+		n0[j] = c0n;
+		int base0 = 0, base1 = c0n;
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			if ((member[j][i] >> lane) & 1ull) {
+				int pos = ((g0[i] >> lane) & 1ull) ? base0 + prefix_count(g0[i]) : base1 + prefix_count(g1[i]);
+				ListEnt e;
+				e.v = v[j][i];
+				e.t = t[j][i];
+				e.pad = 0;
+				lst[j * nm + pos] = e;
+			}
+			base0 += __popcll(g0[i]);
+			base1 += __popcll(g1[i]);
+		}
+	}
+	__syncthreads();
+	// lane k keeps entry k of every list for readlane broadcast
+	double LV[4];
+	int LT[4];
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		ListEnt e = lst[j * nm + (lane < nm ? lane : 0)];
+		LV[j] = e.v;
+		LT[j] = e.t;
+	}
+	STAMP(3);
+
+	// ---- conf(q,1): one edge deviates to any symbol, the others stay at rank 0 (:894) ---------------------------
+	double S[4][4];
+#pragma unroll
+	for (int x = 0; x < 4; x++)
+#pragma unroll
+		for (int i = 0; i < 4; i++) S[x][i] = -NBL_DBL_MAX;
+	const int ztot = ztop[0] ^ ztop[1] ^ ztop[2] ^ ztop[3];
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < 4; i++) U[t[j][i]] = v[j][i];
+		__syncthreads();
+#pragma unroll
+		for (int x = 0; x < 4; x++) {
+			if (x == j) continue;
+			const int shift = ztot ^ ztop[x] ^ ztop[j];
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				double acc = 0.0;
+				const double u = U[sym_of(lane, i) ^ shift];
+#pragma unroll
+				for (int o = 0; o < 4; o++) {
+					if (o == x) continue;
+					acc = acc + ((o == j) ? u : mtop[o]);
+				}
+				S[x][i] = dmax(S[x][i], acc);
+			}
+		}
+	}
+	STAMP(4);
+
+	// ---- conf(nm,nc >= 3): truncated max-plus convolutions; outputs 3,2 share P = e0 (+) e1 ----------------------
+	const int lane16 = lane << 4;
+	auto pair_conv = [&](int ja, int jb) {
+		__syncthreads();
+		double2 ninf;
+		ninf.x = NBL_NEG_INF;
+		ninf.y = NBL_NEG_INF;
+		((double2 *)P)[lane] = ninf;
+		((double2 *)P)[64 + lane] = ninf;
+		__syncthreads();
+		const int total = nm << lognm;
+		for (int idx = lane; idx < total; idx += 64) {
+			const ListEnt ea = lst[ja * nm + (idx & (nm - 1))];
+			const ListEnt eb = lst[jb * nm + (idx >> lognm)];
+			const double val = ea.v + eb.v;
+			__hip_atomic_fetch_max(&P[ea.t ^ eb.t], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		__syncthreads();
+	};
+	auto gather_conv = [&](const double &LVc, const int &LTc, int n0c, double (&Sout)[4]) {
+		double a0 = NBL_NEG_INF, a1 = NBL_NEG_INF, a2 = NBL_NEG_INF, a3 = NBL_NEG_INF;
+		const char *Pb = (const char *)P;
+#pragma unroll 4
+		for (int k = 0; k < n0c; k++) {
+			const int tk = __builtin_amdgcn_readlane(LTc, k);
+			const double vk = read_lane_f64(LVc, k);
+			const int ad = lane16 ^ ((tk & 0xFE) << 3);
+			const double2 ra = *(const double2 *)(Pb + ad);
+			const double2 rb = *(const double2 *)(Pb + (ad ^ 1024));
+			a0 = dmax(a0, ra.x + vk);
+			a1 = dmax(a1, ra.y + vk);
+			a2 = dmax(a2, rb.x + vk);
+			a3 = dmax(a3, rb.y + vk);
+		}
+#pragma unroll 4
+		for (int k = n0c; k < nm; k++) {
+			const int tk = __builtin_amdgcn_readlane(LTc, k);
+			const double vk = read_lane_f64(LVc, k);
+			const int ad = lane16 ^ ((tk & 0xFE) << 3);
+			const double2 ra = *(const double2 *)(Pb + ad);
+			const double2 rb = *(const double2 *)(Pb + (ad ^ 1024));
+			a0 = dmax(a0, ra.y + vk);
+			a1 = dmax(a1, ra.x + vk);
+			a2 = dmax(a2, rb.y + vk);
+			a3 = dmax(a3, rb.x + vk);
+		}
+		Sout[0] = dmax(Sout[0], a0);
+		Sout[1] = dmax(Sout[1], a1);
+		Sout[2] = dmax(Sout[2], a2);
+		Sout[3] = dmax(Sout[3], a3);
+	};
+	// c2v[a] = shape(S[h_x a] - S[0]) (:899-916)
+	auto emit = [&](int x) {
+		__syncthreads();
+		double2 s01, s23;
+		s01.x = S[x][0]; s01.y = S[x][1]; s23.x = S[x][2]; s23.y = S[x][3];
+		((double2 *)Sx)[lane] = s01;
+		((double2 *)Sx)[64 + lane] = s23;
+		__syncthreads();
+		const double s0 = Sx[0];
+		double y[4];
+#pragma unroll
+		for (int i = 0; i < 4; i++) y[i] = shape_llr(Sx[t[x][i]] - s0, r.factor, r.offset);
+		if (lane == 0) y[0] = 0.0;
+		double2 o01, o23;
+		o01.x = y[0]; o01.y = y[1]; o23.x = y[2]; o23.y = y[3];
+		double2 *dst = (double2 *)(C + (size_t)x * Q);
+		dst[lane] = o01;
+		dst[64 + lane] = o23;
+	};
+
+	pair_conv(0, 1);
+	STAMP(5);
+	gather_conv(LV[2], LT[2], n0[2], S[3]);
+	gather_conv(LV[3], LT[3], n0[3], S[2]);
+	STAMP(6);
+	emit(3);
+	emit(2);
+	STAMP(7);
+	pair_conv(0, 2);
+	STAMP(5);
+	gather_conv(LV[3], LT[3], n0[3], S[1]);
+	STAMP(6);
+	emit(1);
+	STAMP(7);
+	pair_conv(1, 2);
+	STAMP(5);
+	gather_conv(LV[3], LT[3], n0[3], S[0]);
+	STAMP(6);
+	emit(0);
+	STAMP(7);
+
+	if (st_on && lane == 0) {
+		for (int i = 0; i < 8; i++) atomicAdd(&w.stamps[i], st_acc[i]);
+		atomicAdd(&w.stamps[15], 1ull);
+	}
+#undef STAMP
+}
+
+bool nbl_ems256_applicable(const NblGraphDev &g, bool all_dc4, int nm, int nc)
+{
+	return g.q == 256 && all_dc4 && nc >= 3 && (nm == 8 || nm == 16 || nm == 32 || nm == 64);
+}
+
+size_t nbl_ems256_lds_bytes(int nm) { return 3 * Q * 8 + (size_t)4 * nm * 16; }
+
+hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
+{
+	int lognm = 0;
+	while ((1 << lognm) < r.nm) lognm++;
+	dim3 grid((unsigned)((long long)r.B * g.M)), block(64);
+	cn_ems_q256_dc4_kernel<<<grid, block, nbl_ems256_lds_bytes(r.nm), st>>>(g, w, r, lognm);
+	return hipGetLastError();
+}

@@ -31,6 +31,7 @@ struct NblWork {
 	int *dec, *out, *iters;
 	uint8_t *done;
 	int *n_done;                    // device counter of converged codewords
+	unsigned long long *stamps;     // [16] debug: per-section cycle sums of the check-node kernel (NULL = off)
 };
 
 struct NblRun {

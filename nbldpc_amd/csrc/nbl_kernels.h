@@ -10,3 +10,8 @@ hipError_t nbl_launch_cn_ems(const NblGraphDev &g, const NblWork &w, const NblRu
 hipError_t nbl_launch_unpad(const double *src, double *dst, const int *map, int rows, int q, hipStream_t st);
 size_t nbl_ems_lds_bytes(const NblGraphDev &g, int nm, int layers);
 int nbl_ems_layers(const NblGraphDev &g, int nc);
+
+// specialised EMS check node (nbl_cn_ems256.hip)
+bool nbl_ems256_applicable(const NblGraphDev &g, bool all_dc4, int nm, int nc);
+size_t nbl_ems256_lds_bytes(int nm);
+hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);

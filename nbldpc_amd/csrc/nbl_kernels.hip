@@ -250,7 +250,12 @@ __global__ __launch_bounds__(64) void cn_ems_kernel(NblGraphDev g, NblWork w, Nb
 	const int b = blockIdx.x / g.M, m = blockIdx.x % g.M;
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m], dc = g.coff[m + 1] - c0;
-	const int nm = r.nm, nc = r.nc;
+	const int nm = r.nm;
+	// debug stamps (diagnostic runs only): cycles per section, summed over sampled blocks
+	unsigned long long st_t0 = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	const bool st_on = (w.stamps != nullptr) && ((blockIdx.x & 63) == 0);
+#define STAMP(i) do { if (st_on) { unsigned long long t1_ = clock64(); st_acc[i] += t1_ - st_t0; st_t0 = t1_; } } while (0)
+	if (st_on) st_t0 = clock64();
 
 	EmsLds s;
 	s.U = (double *)smem;
@@ -280,7 +285,9 @@ __global__ __launch_bounds__(64) void cn_ems_kernel(NblGraphDev g, NblWork w, Nb
 		uint64_t member[NS];
 		double top_v;
 		int top_a;
+		STAMP(0);
 		select_top<NS>(v, lane, Q, nm, member, top_v, top_a);
+		STAMP(1);
 		// compact the members into the list, rank 0 swapped to the front
 		int base = 0, p0 = 0;
 #pragma unroll
@@ -301,6 +308,7 @@ __global__ __launch_bounds__(64) void cn_ems_kernel(NblGraphDev g, NblWork w, Nb
 			}
 			base += __popcll(member[i]);
 		}
+		STAMP(2);
 	}
 	__syncthreads();
 
@@ -332,6 +340,7 @@ __global__ __launch_bounds__(64) void cn_ems_kernel(NblGraphDev g, NblWork w, Nb
 			}
 		}
 
+		STAMP(3);
 		// conf(nm,nc): at most nc edges deviate, each inside its nm best (:897)
 		if (layers == 1) {
 			// nc >= dc-1: no deviation counting needed -> plain truncated max-plus convolution
@@ -352,6 +361,7 @@ __global__ __launch_bounds__(64) void cn_ems_kernel(NblGraphDev g, NblWork w, Nb
 				}
 			}
 			__syncthreads();
+			STAMP(4);
 			for (int l = 2; l < rn; l++) {
 				const int jl = OTH(l);
 				double acc[NS];
@@ -432,6 +442,7 @@ __global__ __launch_bounds__(64) void cn_ems_kernel(NblGraphDev g, NblWork w, Nb
 			}
 		}
 
+		STAMP(5);
 		// ---- output: c2v[a] = shape(S[h_x a] - S[0]) (:899-916) ----------------------------------------------
 		double *Sv = s.Sv;
 #pragma unroll
@@ -452,7 +463,13 @@ __global__ __launch_bounds__(64) void cn_ems_kernel(NblGraphDev g, NblWork w, Nb
 			}
 		}
 #undef OTH
+		STAMP(6);
 	}
+	if (st_on && lane == 0) {
+		for (int i = 0; i < 8; i++) atomicAdd(&w.stamps[i], st_acc[i]);
+		atomicAdd(&w.stamps[15], 1ull);
+	}
+#undef STAMP
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -1,0 +1,24 @@
+"""Diagnostic: in-kernel cycle breakdown of the EMS check-node kernel (not a benchmark)."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import nbldpc_amd as nb
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)) + "/..")
+from bench import synth_llr, CODE
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+code = nb.Code(CODE)
+dec = nb.Decoder(code, nb.METHOD_EMS, 10, ems_nm=32, ems_nc=3, fixed_iters=1, max_batch=B)
+L = synth_llr(torch, 256, 64, B, 1.0, 173, torch.device("cuda", 0)).cpu().numpy()
+dec.decode(L)
+lib = dec.lib
+lib.nbl_debug_stamps.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+out = (C.c_ulonglong * 16)()
+lib.nbl_debug_stamps(dec.h, 1, None)
+dec.decode(L)
+lib.nbl_debug_stamps(dec.h, 0, out)
+n = out[15]
+names = ["load+permute", "select_top", "compact", "conf(q,1)", "pair scatter", "gather conv", "output"]
+tot = sum(out[i] for i in range(7))
+for i, nme in enumerate(names):
+    print(f"{nme:14s} {out[i]/n:10.0f} cycles/check  {100*out[i]/tot:5.1f}%")
+print("total", tot / n, "cycles per check-wave (s_memtime ticks), samples", n)
