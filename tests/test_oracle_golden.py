@@ -1,0 +1,107 @@
+"""The oracle (oracle/nbl_oracle.c) against the golden vectors dumped from the COMPILED REFERENCE.
+
+literal mode  : bit-identical message state, hard decisions and return flags (this is the parity pin)
+canonical mode: identical hard decisions / flags, LLR state within 1e-9 (the reference's add-then-subtract
+                residue, NBLDPC.cpp:1767/1773, is the only difference)
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, decoder_kwargs
+import nbldpc_amd.datafiles as df
+
+ALL_SETS = ["cfg1_bp_gf16", "cfg2_ems_u128", "cfg3_ems_u512", "ems_nc2_shaped", "ems_nc1", "ems_gf16_dc5",
+            "ems_gf16_nc4", "cfg4_tems_bds", "tems_gf16_dc5", "cfg5_bp_c512"]
+FAST_SETS = [s for s in ALL_SETS if s not in ("cfg5_bp_c512",)]
+LLR_TOL = 1e-9
+
+
+def _mk(oracle, meta, max_iter, mode):
+    N, M, q, ev, ec, eh = df.code_edges(meta["code"])
+    code = oracle.Code(edges=(N, M, q, ev, ec, eh))
+    gf = oracle.GF(q)
+    return oracle.Decoder(code, gf, meta["profile"]["method"], int(max_iter), mode, **decoder_kwargs(meta["profile"]))
+
+
+def _check_decisions(oracle, name, mode, max_frames=None):
+    g, meta = load_golden(name)
+    L = g["L_ch"]
+    B = L.shape[0] if max_frames is None else min(max_frames, L.shape[0])
+    for k, it in enumerate(g["iters"]):
+        dec = _mk(oracle, meta, it, mode)
+        for b in range(B):
+            r, out, _ = dec.decode(L[b])
+            assert np.array_equal(out, g["out"][k, b]), (name, int(it), b)
+            assert r == g["syn_ok"][k, b], (name, int(it), b)
+            if meta["profile"]["method"] != 1:  # BP's failure return value is undefined in the reference (NBLDPC.cpp:769-776)
+                assert r == g["ret"][k, b]
+
+
+def _check_state(oracle, name, mode, exact):
+    g, meta = load_golden(name)
+    L = g["L_ch"]
+    for k, it in enumerate(g["state_iters"]):
+        dec = _mk(oracle, meta, it, mode)
+        for li, lane in enumerate(g["state_lanes"]):
+            dec.decode(L[lane])
+            post, v2c, c2v = dec.state()
+            for nm, a, ref in (("post", post, g["st_post"][k, li]), ("v2c", v2c, g["st_v2c"][k, li]), ("c2v", c2v, g["st_c2v"][k, li])):
+                if exact:
+                    assert np.array_equal(a, ref), (name, nm, int(it), int(lane))
+                else:
+                    assert np.max(np.abs(a - ref)) <= LLR_TOL * max(1.0, np.max(np.abs(ref))), (name, nm, int(it), int(lane))
+
+
+@pytest.mark.parametrize("name", FAST_SETS)
+def test_literal_bit_exact(oracle, name):
+    _check_decisions(oracle, name, oracle.LITERAL)
+    _check_state(oracle, name, oracle.LITERAL, exact=True)
+
+
+def test_literal_bit_exact_bp_gf256(oracle):
+    # 80-bit long double box-plus at q = 256: ~2.3 s per iteration per codeword, so one frame, state after 1 iteration
+    g, meta = load_golden("cfg5_bp_c512")
+    dec = _mk(oracle, meta, 1, oracle.LITERAL)
+    r, out, _ = dec.decode(g["L_ch"][0])
+    assert np.array_equal(out, g["out"][0, 0]) and r == g["syn_ok"][0, 0]
+    post, v2c, c2v = dec.state()
+    assert np.array_equal(c2v, g["st_c2v"][0, 0]) and np.array_equal(v2c, g["st_v2c"][0, 0]) and np.array_equal(post, g["st_post"][0, 0])
+
+
+@pytest.mark.parametrize("name", [s for s in FAST_SETS if s != "cfg1_bp_gf16"])
+def test_canonical_matches_reference_decisions(oracle, name):
+    _check_decisions(oracle, name, oracle.CANONICAL, max_frames=8)
+    _check_state(oracle, name, oracle.CANONICAL, exact=False)
+
+
+def test_canonical_bp_gf16(oracle):
+    # double accumulators instead of the reference's 80-bit ones: decisions still agree on the golden frames
+    _check_decisions(oracle, "cfg1_bp_gf16", oracle.CANONICAL)
+
+
+@pytest.mark.parametrize("name", ["cfg2_ems_u128", "ems_nc2_shaped", "ems_nc1", "ems_gf16_dc5", "ems_gf16_nc4"])
+def test_ems_dynamic_program_equals_enumeration(oracle, name):
+    """The max-plus DP (what the HIP kernels implement) equals plain residue-free enumeration bit for bit."""
+    g, meta = load_golden(name)
+    L = g["L_ch"]
+    it = int(g["iters"][-1])
+    a, b = _mk(oracle, meta, it, oracle.CANONICAL), _mk(oracle, meta, it, oracle.CANONICAL_DFS)
+    for f in range(min(4, L.shape[0])):
+        ra, oa, ia = a.decode(L[f])
+        rb, ob, ib = b.decode(L[f])
+        assert (ra, ia) == (rb, ib) and np.array_equal(oa, ob)
+        for x, y in zip(a.state(), b.state()):
+            assert np.array_equal(x, y)
+
+
+def test_fixed_iterations_freeze_output(oracle):
+    g, meta = load_golden("cfg2_ems_u128")
+    L = g["L_ch"]
+    k = len(g["iters"]) - 1
+    N, M, q, ev, ec, eh = df.code_edges(meta["code"])
+    code, gf = oracle.Code(edges=(N, M, q, ev, ec, eh)), oracle.GF(q)
+    kw = decoder_kwargs(meta["profile"])
+    dec = oracle.Decoder(code, gf, 2, int(g["iters"][k]), oracle.LITERAL, fixed_iters=1, **kw)
+    for b in range(4):
+        r, out, it = dec.decode(L[b])
+        assert np.array_equal(out, g["out"][k, b]) and r == g["syn_ok"][k, b]
