@@ -1,5 +1,5 @@
 // nbldpc_amd/csrc/nbl_cn_ems256.hip -- EMS check node specialised for the headline shape:
-//   GF(256), every check of degree 4, nc >= 3 (no deviation counting), nm in {8,16,32,64}.
+//   GF(256), every check of degree 4, nc >= 3 (no deviation counting), nm in {8,16,32}.
 // (BASELINE configs 2 and 3: divsalar.UNBLDPC.{128.64,512.256}.GF.256, EMS nm=16/32.)
 //
 // Same arithmetic as cn_ems_kernel<256> (nbl_kernels.hip) -- the generic kernel is the readable statement of the
@@ -11,7 +11,9 @@
 //     wave at nm = 32, four waves per SIMD.
 //   * the nm-best lists are packed {value, symbol} 16-byte entries, split by bit 0 of the symbol so the pair swap
 //     of the gather is resolved by loop structure instead of per-element selects.
-//   * top-nm selection: ballot quickselect with candidate sets in scalar registers, two edges interleaved.
+//   * top-nm selection without sorting: a 64-bucket histogram (LDS atomics + DPP prefix sum) finds the bucket that
+//     holds the nm-th best value, a ballot quickselect inside that bucket finds the exact cut under SortLLRVector's
+//     order (value desc, higher symbol first among equals).
 #include <hip/hip_runtime.h>
 #include "nbl_device.h"
 #include "nbl_kernels.h"
@@ -20,7 +22,8 @@ namespace {
 
 constexpr int Q = 256;
 
-struct __attribute__((aligned(16))) ListEnt { double v; int t; int pad; };
+struct __attribute__((aligned(16))) ListEnt { double v; int t; int tt; };   // tt = (t & 0xFE) << 3: byte offset XOR of the gather
+struct __attribute__((aligned(16))) CandEnt { double v; int a; int pad; };
 
 // ---- 64-bit wave max through DPP moves (no LDS) ------------------------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xF>
@@ -40,6 +43,41 @@ __device__ __forceinline__ double wave_max_f64(double x)
 	x = dmax(x, dpp_mov_f64<0x142, 0xA>(x));  // row_bcast15 into rows 1,3
 	x = dmax(x, dpp_mov_f64<0x143, 0xC>(x));  // row_bcast31 into rows 2,3
 	return read_lane_f64(x, 63);
+}
+
+__device__ __forceinline__ double wave_min_f64(double x)
+{
+	x = dmin(x, dpp_mov_f64<0xB1>(x));
+	x = dmin(x, dpp_mov_f64<0x4E>(x));
+	x = dmin(x, dpp_mov_f64<0x141>(x));
+	x = dmin(x, dpp_mov_f64<0x140>(x));
+	x = dmin(x, dpp_mov_f64<0x142, 0xA>(x));
+	x = dmin(x, dpp_mov_f64<0x143, 0xC>(x));
+	return read_lane_f64(x, 63);
+}
+
+// inclusive prefix sum over the 64 lanes (the DPP sequence LLVM's atomic optimiser emits on gfx9)
+__device__ __forceinline__ int wave_scan_add(int x)
+{
+	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); // row_shr:1
+	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false); // row_shr:2
+	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false); // row_shr:4
+	x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false); // row_shr:8
+	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false); // row_bcast15 -> rows 1,3
+	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false); // row_bcast31 -> rows 2,3
+	return x;
+}
+
+__device__ __forceinline__ int wave_max_i32(int x)
+{
+	auto mx = [](int a, int b) { return a > b ? a : b; };
+	x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));
+	x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));
+	x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));
+	x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false));
+	x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xA, 0xF, false));
+	x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xC, 0xF, false));
+	return __builtin_amdgcn_readlane(x, 63);
 }
 
 // symbol of slot i of lane l in this kernel's layout
@@ -96,14 +134,14 @@ struct SelState {
 	int done;
 };
 
-// one quickselect step for one edge; everything except the compares is scalar
+// one quickselect step for one edge: pivot = first remaining candidate, counts by ballot
 __device__ __forceinline__ void select_step(const double (&v)[4], int nm, SelState &s)
 {
 	if (s.done) return;
 	const uint64_t any = s.cand[0] | s.cand[1] | s.cand[2] | s.cand[3];
 	if (!any) { s.done = 1; return; } // only reachable with NaN inputs
-	// every lane offers its first remaining candidate; the pivot is the offer of the first lane that has one
-	double offer = (s.cand[0] >> lane_id()) & 1 ? v[0] : (s.cand[1] >> lane_id()) & 1 ? v[1] : (s.cand[2] >> lane_id()) & 1 ? v[2] : v[3];
+	double offer = __builtin_amdgcn_inverse_ballot_w64(s.cand[0]) ? v[0] : __builtin_amdgcn_inverse_ballot_w64(s.cand[1]) ? v[1]
+	             : __builtin_amdgcn_inverse_ballot_w64(s.cand[2]) ? v[2] : v[3];
 	const double pv = read_lane_f64(offer, __builtin_ctzll(any));
 	uint64_t gt[4], ge[4];
 	int cgt = 0, cge = 0;
@@ -127,7 +165,7 @@ __device__ __forceinline__ void select_step(const double (&v)[4], int nm, SelSta
 	}
 }
 
-// members of the nm best under SortLLRVector's order (value desc, higher symbol first among equals)
+// members of the nm best under SortLLRVector's order (value desc, higher symbol first among equals, NBLDPC.cpp:1731)
 __device__ __forceinline__ void finish_members(SelState &s, int nm, uint64_t (&member)[4])
 {
 	int cgt = 0, ceq = 0;
@@ -154,21 +192,24 @@ __device__ __forceinline__ void finish_members(SelState &s, int nm, uint64_t (&m
 
 } // namespace
 
-__global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r, int lognm)
+template <int NM>
+__global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
+	constexpr int LOGNM = (NM == 8) ? 3 : (NM == 16) ? 4 : 5;
+	constexpr int NMP = NM + 8; // padded list: [even-symbol group | pad to 4 | odd-symbol group | pad to 4]
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int lane = lane_id();
 	const int b = blockIdx.x / g.M, m = blockIdx.x % g.M;
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m];
-	const int nm = r.nm;
 
-	double *U = (double *)smem;          // [256] check-domain copy of one input vector
-	double *P = U + Q;                   // [256] pair convolution
-	double *Sx = P + Q;                  // [256] final maxima of one output edge
-	ListEnt *lst = (ListEnt *)(Sx + Q);  // [4][nm]
+	double *U = (double *)smem;              // [256] check-domain copy of one input vector | histogram | S of one output
+	double *P = U + Q;                       // [256] pair convolution (U..P together: candidate buffer of the selection)
+	ListEnt *lst = (ListEnt *)(P + Q);       // [4][NM]   the nm best of every edge, contiguous (pair convolution)
+	ListEnt *lstp = lst + 4 * NM;            // [4][NMP]  same entries grouped by symbol bit 0 and padded (gather)
+	int *misc = (int *)(lstp + 4 * NMP);     // [4] scratch counters
 
-	unsigned long long st_t0 = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long st_t0 = 0, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	const bool st_on = (w.stamps != nullptr) && ((blockIdx.x & 63) == 0);
 #define STAMP(i) do { if (st_on) { unsigned long long t1_ = clock64(); st_acc[i] += t1_ - st_t0; st_t0 = t1_; } } while (0)
 	if (st_on) st_t0 = clock64();
@@ -199,79 +240,126 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	}
 	STAMP(0);
 
-	// ---- rank 0 of every edge: value m_j, check-domain symbol z_j ---------------------------------------------------
-	double mtop[4];
+	// ---- rank 0 of every edge: value m_j, check-domain symbol z_j (highest symbol among equal maxima, :1731) -------
+	double mtop[4], lmin[4];
 	int ztop[4];
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
 		double loc = dmax(dmax(v[j][0], v[j][1]), dmax(v[j][2], v[j][3]));
 		mtop[j] = wave_max_f64(loc);
-		uint64_t eq[4];
+		lmin[j] = wave_min_f64(loc); // 64 distinct entries are >= lmin, so the nm-th best (nm <= 64) is too
+		int besta = -1;
 #pragma unroll
-		for (int i = 0; i < 4; i++) eq[i] = __ballot(v[j][i] == mtop[j]);
-		int a = highest_sym(eq);
-		GfMulL mh;
-		ztop[j] = mh.scalar(a, hcoef[j], g.poly);
+		for (int i = 0; i < 4; i++) besta = (v[j][i] == mtop[j]) ? sym_of(lane, i) : besta; // slots ascend in symbol
+		const int topa = wave_max_i32(besta);
+		ztop[j] = g.mul[hcoef[j] * Q + topa];
 	}
 	STAMP(1);
 
-	// ---- top-nm selection, two edges interleaved -------------------------------------------------------------------
-	uint64_t member[4][4];
+	// ---- top-nm selection -------------------------------------------------------------------------------------------
+	// (a) a 64-bucket histogram of [lmin, mtop] (LDS atomics + DPP prefix sum) finds the bucket that holds the nm-th best
+	// value -- bucketing only has to be monotone, so its arithmetic needs no care; (b) a ballot quickselect, restricted to
+	// that bucket, finds the cut exactly; ties at the cut are resolved by symbol, higher first (:1731).
+	bool mem[4][4];
+	{
+		int bk[4][4];
+		int *H = (int *)U; // [64 buckets][4 edges]
+		int4 z4 = {0, 0, 0, 0};
+		((int4 *)H)[lane] = z4;
+		__syncthreads();
 #pragma unroll
-	for (int jp = 0; jp < 4; jp += 2) {
-		SelState s0, s1;
+		for (int j = 0; j < 4; j++) {
+			const double range = mtop[j] - lmin[j];
+			const double scale = range > 0.0 ? 64.0 / range : 0.0;
 #pragma unroll
-		for (int i = 0; i < 4; i++) { s0.cand[i] = ~0ull; s1.cand[i] = ~0ull; s0.gt[i] = s0.eq[i] = s1.gt[i] = s1.eq[i] = 0; }
-		s0.done = s1.done = 0;
-		for (int guard = 0; guard < 300 && !(s0.done && s1.done); guard++) {
-			select_step(v[jp], nm, s0);
-			select_step(v[jp + 1], nm, s1);
+			for (int i = 0; i < 4; i++) {
+				const double d = (mtop[j] - v[j][i]) * scale;
+				int bi = (int)dmin(d, 63.0);
+				bk[j][i] = (v[j][i] >= lmin[j]) ? bi : 64;
+				if (bk[j][i] < 64) atomicAdd(&H[bk[j][i] * 4 + j], 1);
+			}
 		}
-		finish_members(s0, nm, member[jp]);
-		finish_members(s1, nm, member[jp + 1]);
+		__syncthreads();
+		int4 cnt4 = ((int4 *)H)[lane];
+		const int cnt[4] = {cnt4.x, cnt4.y, cnt4.z, cnt4.w};
+		STAMP(2);
+#pragma unroll
+		for (int jp = 0; jp < 4; jp += 2) {
+			SelState ss[2];
+#pragma unroll
+			for (int u = 0; u < 2; u++) {
+				const int j = jp + u;
+				const int cum = wave_scan_add(cnt[j]);
+				const uint64_t reach = __ballot(cum >= NM);
+				const int bstar = reach ? __builtin_ctzll(reach) : 63;
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					ss[u].cand[i] = __ballot(bk[j][i] == bstar);
+					ss[u].gt[i] = ss[u].eq[i] = 0;
+				}
+				ss[u].done = 0;
+			}
+			for (int guard = 0; guard < 300 && !(ss[0].done && ss[1].done); guard++) {
+				select_step(v[jp], NM, ss[0]);
+				select_step(v[jp + 1], NM, ss[1]);
+				if (st_on) st_acc[9]++;
+			}
+#pragma unroll
+			for (int u = 0; u < 2; u++) {
+				uint64_t member[4];
+				finish_members(ss[u], NM, member);
+#pragma unroll
+				for (int i = 0; i < 4; i++) mem[jp + u][i] = __builtin_amdgcn_inverse_ballot_w64(member[i]);
+			}
+		}
 	}
-	STAMP(2);
+	STAMP(3);
 
-	// ---- compact members into packed lists, entries with symbol bit 0 clear first ---------------------------------
-	int n0[4];
+	// ---- compact the members into the two list images ---------------------------------------------------------------
+	int n0p[4], n1p[4];
+	__syncthreads();
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
 		uint64_t g0[4], g1[4];
 		int c0n = 0;
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
-			uint64_t even = __ballot((t[j][i] & 1) == 0);
-			g0[i] = member[j][i] & even;
-			g1[i] = member[j][i] & ~even;
+			g0[i] = __ballot(mem[j][i] && (t[j][i] & 1) == 0);
+			g1[i] = __ballot(mem[j][i] && (t[j][i] & 1) != 0);
 			c0n += __popcll(g0[i]);
 		}
-		n0[j] = c0n;
-		int base0 = 0, base1 = c0n;
+		const int n0 = c0n, n1 = NM - c0n;
+		n0p[j] = (n0 + 3) & ~3;
+		n1p[j] = (n1 + 3) & ~3;
+		// pads first (never win a max), members overwrite nothing of them
+		if (lane < 8) {
+			ListEnt pe;
+			pe.v = NBL_NEG_INF;
+			pe.t = 0;
+			pe.tt = 0;
+			const int pos = (lane < 4) ? n0 + lane : n0p[j] + n1 + (lane - 4);
+			const bool need = (lane < 4) ? (n0 + lane < n0p[j]) : (n1 + lane - 4 < n1p[j]);
+			if (need) lstp[j * NMP + pos] = pe;
+		}
+		int base0 = 0, base1 = 0;
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
-			if ((member[j][i] >> lane) & 1ull) {
-				int pos = ((g0[i] >> lane) & 1ull) ? base0 + prefix_count(g0[i]) : base1 + prefix_count(g1[i]);
+			if (mem[j][i]) {
+				const bool ev = (t[j][i] & 1) == 0;
+				const int pg = ev ? base0 + prefix_count(g0[i]) : base1 + prefix_count(g1[i]);
 				ListEnt e;
 				e.v = v[j][i];
 				e.t = t[j][i];
-				e.pad = 0;
-				lst[j * nm + pos] = e;
+				e.tt = (t[j][i] & 0xFE) << 3;
+				lst[j * NM + (ev ? pg : n0 + pg)] = e;
+				lstp[j * NMP + (ev ? pg : n0p[j] + pg)] = e;
 			}
 			base0 += __popcll(g0[i]);
 			base1 += __popcll(g1[i]);
 		}
 	}
 	__syncthreads();
-	// lane k keeps entry k of every list for readlane broadcast
-	double LV[4];
-	int LT[4];
-#pragma unroll
-	for (int j = 0; j < 4; j++) {
-		ListEnt e = lst[j * nm + (lane < nm ? lane : 0)];
-		LV[j] = e.v;
-		LT[j] = e.t;
-	}
-	STAMP(3);
+	STAMP(4);
 
 	// ---- conf(q,1): one edge deviates to any symbol, the others stay at rank 0 (:894) ---------------------------
 	double S[4][4];
@@ -303,7 +391,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			}
 		}
 	}
-	STAMP(4);
+	STAMP(5);
 
 	// ---- conf(nm,nc >= 3): truncated max-plus convolutions; outputs 3,2 share P = e0 (+) e1 ----------------------
 	const int lane16 = lane << 4;
@@ -314,42 +402,58 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		ninf.y = NBL_NEG_INF;
 		((double2 *)P)[lane] = ninf;
 		((double2 *)P)[64 + lane] = ninf;
+		const ListEnt ea = lst[ja * NM + (lane & (NM - 1))];
 		__syncthreads();
-		const int total = nm << lognm;
-		for (int idx = lane; idx < total; idx += 64) {
-			const ListEnt ea = lst[ja * nm + (idx & (nm - 1))];
-			const ListEnt eb = lst[jb * nm + (idx >> lognm)];
-			const double val = ea.v + eb.v;
-			__hip_atomic_fetch_max(&P[ea.t ^ eb.t], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		constexpr int PER = 64 >> LOGNM, ROUNDS = (NM << LOGNM) >> 6;
+#pragma unroll
+		for (int it = 0; it < ROUNDS; it++) {
+			const ListEnt eb = lst[jb * NM + it * PER + (lane >> LOGNM)];
+			__hip_atomic_fetch_max(&P[ea.t ^ eb.t], ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 		__syncthreads();
 	};
-	auto gather_conv = [&](const double &LVc, const int &LTc, int n0c, double (&Sout)[4]) {
+	auto gather_conv = [&](int jc, double (&Sout)[4]) {
 		double a0 = NBL_NEG_INF, a1 = NBL_NEG_INF, a2 = NBL_NEG_INF, a3 = NBL_NEG_INF;
 		const char *Pb = (const char *)P;
-#pragma unroll 4
-		for (int k = 0; k < n0c; k++) {
-			const int tk = __builtin_amdgcn_readlane(LTc, k);
-			const double vk = read_lane_f64(LVc, k);
-			const int ad = lane16 ^ ((tk & 0xFE) << 3);
-			const double2 ra = *(const double2 *)(Pb + ad);
-			const double2 rb = *(const double2 *)(Pb + (ad ^ 1024));
-			a0 = dmax(a0, ra.x + vk);
-			a1 = dmax(a1, ra.y + vk);
-			a2 = dmax(a2, rb.x + vk);
-			a3 = dmax(a3, rb.y + vk);
+		const ListEnt *L = lstp + jc * NMP;
+		const int e0 = n0p[jc], e1 = n0p[jc] + n1p[jc];
+		for (int k = 0; k < e0; k += 4) {
+			ListEnt en[4];
+			double2 ra[4], rb[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) en[u] = L[k + u]; // same address in every lane: LDS broadcast
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int ad = lane16 ^ en[u].tt;
+				ra[u] = *(const double2 *)(Pb + ad);
+				rb[u] = *(const double2 *)(Pb + (ad ^ 1024));
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				a0 = dmax(a0, ra[u].x + en[u].v);
+				a1 = dmax(a1, ra[u].y + en[u].v);
+				a2 = dmax(a2, rb[u].x + en[u].v);
+				a3 = dmax(a3, rb[u].y + en[u].v);
+			}
 		}
-#pragma unroll 4
-		for (int k = n0c; k < nm; k++) {
-			const int tk = __builtin_amdgcn_readlane(LTc, k);
-			const double vk = read_lane_f64(LVc, k);
-			const int ad = lane16 ^ ((tk & 0xFE) << 3);
-			const double2 ra = *(const double2 *)(Pb + ad);
-			const double2 rb = *(const double2 *)(Pb + (ad ^ 1024));
-			a0 = dmax(a0, ra.y + vk);
-			a1 = dmax(a1, ra.x + vk);
-			a2 = dmax(a2, rb.y + vk);
-			a3 = dmax(a3, rb.x + vk);
+		for (int k = e0; k < e1; k += 4) {
+			ListEnt en[4];
+			double2 ra[4], rb[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) en[u] = L[k + u];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int ad = lane16 ^ en[u].tt;
+				ra[u] = *(const double2 *)(Pb + ad);
+				rb[u] = *(const double2 *)(Pb + (ad ^ 1024));
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				a0 = dmax(a0, ra[u].y + en[u].v);
+				a1 = dmax(a1, ra[u].x + en[u].v);
+				a2 = dmax(a2, rb[u].y + en[u].v);
+				a3 = dmax(a3, rb[u].x + en[u].v);
+			}
 		}
 		Sout[0] = dmax(Sout[0], a0);
 		Sout[1] = dmax(Sout[1], a1);
@@ -358,6 +462,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	};
 	// c2v[a] = shape(S[h_x a] - S[0]) (:899-916)
 	auto emit = [&](int x) {
+		double *Sx = U;
 		__syncthreads();
 		double2 s01, s23;
 		s01.x = S[x][0]; s01.y = S[x][1]; s23.x = S[x][2]; s23.y = S[x][3];
@@ -377,28 +482,28 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	};
 
 	pair_conv(0, 1);
-	STAMP(5);
-	gather_conv(LV[2], LT[2], n0[2], S[3]);
-	gather_conv(LV[3], LT[3], n0[3], S[2]);
 	STAMP(6);
+	gather_conv(2, S[3]);
+	gather_conv(3, S[2]);
+	STAMP(7);
 	emit(3);
 	emit(2);
-	STAMP(7);
+	STAMP(8);
 	pair_conv(0, 2);
-	STAMP(5);
-	gather_conv(LV[3], LT[3], n0[3], S[1]);
 	STAMP(6);
+	gather_conv(3, S[1]);
+	STAMP(7);
 	emit(1);
-	STAMP(7);
+	STAMP(8);
 	pair_conv(1, 2);
-	STAMP(5);
-	gather_conv(LV[3], LT[3], n0[3], S[0]);
 	STAMP(6);
-	emit(0);
+	gather_conv(3, S[0]);
 	STAMP(7);
+	emit(0);
+	STAMP(8);
 
 	if (st_on && lane == 0) {
-		for (int i = 0; i < 8; i++) atomicAdd(&w.stamps[i], st_acc[i]);
+		for (int i = 0; i < 12; i++) atomicAdd(&w.stamps[i], st_acc[i]);
 		atomicAdd(&w.stamps[15], 1ull);
 	}
 #undef STAMP
@@ -406,16 +511,20 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 
 bool nbl_ems256_applicable(const NblGraphDev &g, bool all_dc4, int nm, int nc)
 {
-	return g.q == 256 && all_dc4 && nc >= 3 && (nm == 8 || nm == 16 || nm == 32 || nm == 64);
+	return g.q == 256 && all_dc4 && nc >= 3 && (nm == 8 || nm == 16 || nm == 32);
 }
 
-size_t nbl_ems256_lds_bytes(int nm) { return 3 * Q * 8 + (size_t)4 * nm * 16; }
+size_t nbl_ems256_lds_bytes(int nm) { return 2 * Q * 8 + (size_t)4 * nm * 16 + (size_t)4 * (nm + 8) * 16 + 16; }
 
 hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
 {
-	int lognm = 0;
-	while ((1 << lognm) < r.nm) lognm++;
 	dim3 grid((unsigned)((long long)r.B * g.M)), block(64);
-	cn_ems_q256_dc4_kernel<<<grid, block, nbl_ems256_lds_bytes(r.nm), st>>>(g, w, r, lognm);
+	const size_t lds = nbl_ems256_lds_bytes(r.nm);
+	switch (r.nm) {
+	case 8: cn_ems_q256_dc4_kernel<8><<<grid, block, lds, st>>>(g, w, r); break;
+	case 16: cn_ems_q256_dc4_kernel<16><<<grid, block, lds, st>>>(g, w, r); break;
+	case 32: cn_ems_q256_dc4_kernel<32><<<grid, block, lds, st>>>(g, w, r); break;
+	default: return hipErrorInvalidValue;
+	}
 	return hipGetLastError();
 }

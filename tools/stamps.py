@@ -17,8 +17,9 @@ lib.nbl_debug_stamps(dec.h, 1, None)
 dec.decode(L)
 lib.nbl_debug_stamps(dec.h, 0, out)
 n = out[15]
-names = ["load+permute", "select_top", "compact", "conf(q,1)", "pair scatter", "gather conv", "output"]
-tot = sum(out[i] for i in range(7))
+names = ["load+permute", "rank0", "histogram", "quickselect", "compact+lists", "conf(q,1)", "pair scatter", "gather conv", "emit"]
+tot = sum(out[i] for i in range(9))
+print("quickselect loop iterations per check:", out[9] / n)
 for i, nme in enumerate(names):
     print(f"{nme:14s} {out[i]/n:10.0f} cycles/check  {100*out[i]/tot:5.1f}%")
 print("total", tot / n, "cycles per check-wave (s_memtime ticks), samples", n)
