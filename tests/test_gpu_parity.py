@@ -18,6 +18,7 @@ import nbldpc_amd.datafiles as df
 pytestmark = pytest.mark.gpu
 
 EMS_SETS = ["cfg2_ems_u128", "cfg3_ems_u512", "ems_nc2_shaped", "ems_nc1", "ems_gf16_dc5", "ems_gf16_nc4"]
+TEMS_SETS = ["cfg4_tems_bds", "tems_gf16_dc5"]
 LLR_TOL = 1e-9
 
 
@@ -33,8 +34,10 @@ def _oracle_decoder(oracle, meta, max_iter, fixed=0):
 
 
 @pytest.mark.parametrize("generic", [False, True])
-@pytest.mark.parametrize("name", EMS_SETS)
+@pytest.mark.parametrize("name", EMS_SETS + TEMS_SETS)
 def test_decisions_equal_reference(name, generic):
+    if generic and name in TEMS_SETS:
+        pytest.skip("T-EMS has one kernel")
     g, meta = load_golden(name)
     p, kw = meta["profile"], decoder_kwargs(meta["profile"])
     code = nb.Code(meta["code"])
@@ -49,8 +52,10 @@ def test_decisions_equal_reference(name, generic):
 
 
 @pytest.mark.parametrize("generic", [False, True])
-@pytest.mark.parametrize("name", EMS_SETS)
+@pytest.mark.parametrize("name", EMS_SETS + TEMS_SETS)
 def test_state_bit_exact_vs_oracle_and_close_to_reference(oracle, name, generic):
+    if generic and name in TEMS_SETS:
+        pytest.skip("T-EMS has one kernel")
     g, meta = load_golden(name)
     p, kw = meta["profile"], decoder_kwargs(meta["profile"])
     code = nb.Code(meta["code"])
