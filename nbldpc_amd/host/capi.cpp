@@ -1,0 +1,78 @@
+// nbldpc_amd/host/capi.cpp -- small C entry points over the host layer for the Python tests (ctypes).
+#include <cstring>
+#include "link.h"
+
+extern "C" {
+
+// Run the link chain of every lane for `frames` cycles WITHOUT decoding and return what the reference's chain produced:
+// L_ch [frames*P][N][q-1] (frame-major, b = f*P + lane), tx_code [frames*P][N], tx_msg [frames*P][K].  No GPU needed.
+int nblh_frontend(const char *profile, double ebn0, int frames, double *L_ch, int *tx_code, int *tx_msg, double *sigma_out)
+{
+	CSimulation sim;
+	if (sim.Initial(profile) != 0) return -1;
+	sim.EbN0 = ebn0;
+	// host-only CNBLDPC use: parse + encoder, no device (Initial would need a GPU) -> replicate the needed part
+	CLink link;
+	link.sim = sim;
+	CNBLDPC &code = link.code;
+	// Initial() creates the device decoder; for the front-end we only need the graph and the encoder, so a failure to
+	// create the device handle is tolerated here (and only here).
+	bool ok = code.Initial(link.sim, 0);
+	if (!ok && code.CodeLen == 0) return -2;
+	const int P = sim.parallel, N = code.CodeLen, K = code.CodeLen - code.ChkLen, w = code.GFq - 1;
+	std::vector<std::unique_ptr<CComm>> lanes;
+	for (int i = 0; i < P; i++) {
+		lanes.emplace_back(new CComm());
+		if (!lanes.back()->Initial(link.sim, i, &code)) return -3;
+		lanes.back()->SetEbN0(link.sim, i);
+	}
+	if (sigma_out) *sigma_out = lanes[0]->sigma_n;
+	for (int f = 0; f < frames; f++)
+		for (int i = 0; i < P; i++) {
+			CComm &c = *lanes[i];
+			c.FrontEnd();
+			const size_t b = (size_t)f * P + i;
+			memcpy(L_ch + b * N * w, c.RX_LLR_SYM.data(), sizeof(double) * N * w);
+			for (int n = 0; n < N; n++) tx_code[b * N + n] = c.TX_CODE_SYM[n];
+			for (int n = 0; n < K; n++) tx_msg[b * K + n] = c.TX_MSG_SYM[n];
+		}
+	return 0;
+}
+
+// Full simulation of one profile on the GPU; per Eb/N0 point: EbN0, errFrame, errSym, errBit, U_errFrame, frames, BER, SER, FER.
+int nblh_simulate(const char *profile, int device, double *rows, int max_rows)
+{
+	CLink link;
+	if (!link.Initial(profile, device)) return -1;
+	int n = 0;
+	while (link.sim.NextSNR()) {
+		link.BeginSNR();
+		while (link.sim.SimulateThisSNR())
+			if (!link.Cycle()) return -2;
+		if (n < max_rows) {
+			double *r = rows + 9 * n;
+			r[0] = link.sim.EbN0; r[1] = link.sim.errFrame; r[2] = link.sim.errSym; r[3] = link.sim.errBit; r[4] = link.sim.U_errFrame;
+			r[5] = (link.sim.simCycle - 1) * link.sim.parallel; r[6] = link.sim.BER; r[7] = link.sim.SER; r[8] = link.sim.FER;
+		}
+		n++;
+	}
+	return n;
+}
+
+// encoder check: encode `count` random messages, return 0 if every codeword satisfies every parity check
+int nblh_encode(const char *profile, const int *msg, int count, int *code_out)
+{
+	CSimulation sim;
+	if (sim.Initial(profile) != 0) return -1;
+	CNBLDPC code;
+	code.Initial(sim, 0);
+	if (code.CodeLen == 0) return -2;
+	const int N = code.CodeLen, K = N - code.ChkLen;
+	std::vector<int> m(K);
+	for (int c = 0; c < count; c++) {
+		memcpy(m.data(), msg + (size_t)c * K, sizeof(int) * K);
+		code.Encode(m.data(), code_out + (size_t)c * N);
+	}
+	return 0;
+}
+}

@@ -1,0 +1,276 @@
+// nbldpc_amd/host/comm.cpp -- see comm.h.  Every arithmetic expression that feeds the channel LLRs keeps the reference's
+// operation order, because L_ch has to be bit-identical for FER parity (tests/test_host_frontend.py).
+#include "comm.h"
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+// seed + lane for the three generators, PN register pre-advanced lane steps (Comm.cpp:58-74, :160-173)
+void CComm::ResetSources(CSimulation &sim, int lane)
+{
+	Rand.IX = Rand.IY = Rand.IZ = sim.randomseed;
+	if (lane) { Rand.IX += lane; Rand.IY += lane; Rand.IZ += lane; }
+	static const int init[11] = {1, 0, 1, 0, 0, 0, 1, 1, 0, 0, 1};
+	memcpy(regPN, init, sizeof init);
+	for (int k = 0; k < lane; k++) GenPN();
+}
+
+bool CComm::Initial(CSimulation &sim, int lane, CNBLDPC *shared)
+{
+	NBLDPC = shared;
+	GFq = sim.GFq;
+	parallel_num = sim.parallel;
+	Bit_Len_PerSYM = log(GFq) / log(2);
+	ResetSources(sim, lane);
+	randomMsg = sim.randomMsg;
+	crcLen = sim.crcLen;
+	crcLen_correct = sim.crc_correctLen;
+
+	MSG_SYM_LEN = NBLDPC->CodeLen - NBLDPC->ChkLen;
+	MSG_BIT_LEN = MSG_SYM_LEN * Bit_Len_PerSYM;
+	CODE_SYM_LEN = NBLDPC->CodeLen;
+	CODE_BIT_LEN = CODE_SYM_LEN * Bit_Len_PerSYM;
+	PUN_SYM_LEN = NBLDPC->PunctureLen;
+	PUN_BIT_LEN = PUN_SYM_LEN * Bit_Len_PerSYM;
+	if (MSG_BIT_LEN - crcLen < 0) { error = "crcLen exceeds the message length"; return false; }
+	TX_MSG_BIT.assign(MSG_BIT_LEN, 0);
+	TX_MSG_SYM.assign(MSG_SYM_LEN, 0);
+	TX_MSG_BIT_beforeCRC.assign(MSG_BIT_LEN - crcLen, 0);
+	TX_CODE_SYM.assign(CODE_SYM_LEN, 0);
+	TX_CODE_BIT.assign(CODE_BIT_LEN, 0);
+	PUN_SYM.assign(PUN_SYM_LEN, 0);
+	PUN_BIT.assign(PUN_BIT_LEN, 0);
+	CodeRate = double(MSG_SYM_LEN) / double(CODE_SYM_LEN - PUN_SYM_LEN);
+	for (int s = 0; s < PUN_SYM_LEN; s++) {
+		PUN_SYM[s] = NBLDPC->PuncturePosition[s];
+		for (int k = 0; k < Bit_Len_PerSYM; k++) PUN_BIT[s * Bit_Len_PerSYM + k] = Bit_Len_PerSYM * NBLDPC->PuncturePosition[s] + k;
+	}
+	modOrder = sim.nQAM;
+	MOD_BIT_PER_SYM = log(sim.nQAM * 1.0) / log(2.0);
+	MOD_SYM_LEN = (CODE_SYM_LEN - PUN_SYM_LEN) * Bit_Len_PerSYM / MOD_BIT_PER_SYM;
+	MOD_BIT_LEN = MOD_SYM_LEN * MOD_BIT_PER_SYM;
+	if (modOrder != 2 && modOrder != GFq) {
+		error = "This module ( code order ~= modulation order ) haven't been developed!"; // Comm.cpp:400-404
+		std::cerr << error << std::endl;
+		return false;
+	}
+
+	// constellation file: "Point: i Real: x Imag: y" per line (Comm.cpp:113-126)
+	CONSTELLATION.assign(modOrder, CComplex());
+	std::ifstream fc(sim.ConstellationFileName);
+	if (!fc.is_open()) { error = "Cannot open " + sim.ConstellationFileName; std::cerr << error << std::endl; return false; }
+	for (int k = 0; k < modOrder; k++) {
+		std::string w;
+		int idx = 0;
+		double re = 0, im = 0;
+		fc >> w >> idx >> w >> re >> w >> im;
+		if (!fc || idx < 0 || idx >= modOrder) { error = "Malformed constellation file"; return false; }
+		CONSTELLATION[idx].Real = re;
+		CONSTELLATION[idx].Image = im;
+	}
+	TX_MOD_BIT.assign(MOD_BIT_LEN, 0);
+	TX_MOD_SYM.assign(MOD_SYM_LEN, CComplex());
+	RX_MOD_SYM.assign(MOD_SYM_LEN, CComplex());
+	RX_LLR_BIT.assign(CODE_BIT_LEN, 0.0);
+	RX_LLR_SYM.assign((size_t)CODE_SYM_LEN * (GFq - 1), 0.0);
+	RX_DECODE_SYM.assign(CODE_SYM_LEN, 0);
+	RX_DECODE_BIT.assign(CODE_BIT_LEN, 0);
+	RX_MSG_SYM.assign(MSG_SYM_LEN, 0);
+	RX_MSG_BIT.assign(MSG_BIT_LEN, 0);
+	return true;
+}
+
+double CComm::SetEbN0(CSimulation &sim, int lane)
+{
+	ResetSources(sim, lane);
+	double EbN0 = pow(10.0, sim.EbN0 / 10.0);
+	sigma_n = 1.0 / sqrt(2 * MOD_BIT_PER_SYM * CodeRate * EbN0); // Comm.cpp:176-177
+	return sigma_n;
+}
+
+int CComm::FrontEnd()
+{
+	GenerateMessage();
+	Encode();
+	Puncture();
+	Modulate();
+	Channel_AWGN();
+	return Demodulate();
+}
+
+// 11-stage shift register, output r10, feedback r10 ^ r3 after the shift (Comm.cpp:241-252)
+int CComm::GenPN()
+{
+	for (int i = 10; i >= 1; i--) regPN[i] = regPN[i - 1];
+	regPN[0] = regPN[10] ^ regPN[3];
+	return regPN[10];
+}
+
+// every lane draws from the SAME PN sequence, interleaved: lane i uses outputs i, i+P, i+2P, .. (Comm.cpp:199-202)
+int CComm::GenerateMessage()
+{
+	const int nb = MSG_BIT_LEN - crcLen;
+	for (int b = 0; b < nb; b++) {
+		if (randomMsg) {
+			for (int k = 0; k < parallel_num - 1; k++) GenPN();
+			TX_MSG_BIT_beforeCRC[b] = GenPN();
+		} else {
+			TX_MSG_BIT_beforeCRC[b] = 0;
+		}
+	}
+	CRCEncode(TX_MSG_BIT.data(), TX_MSG_BIT_beforeCRC.data(), nb, crcLen, 0);
+	for (int s = 0; s < MSG_SYM_LEN; s++) {
+		int sym = 0;
+		for (int k = Bit_Len_PerSYM - 1; k >= 0; k--) sym = 2 * sym + TX_MSG_BIT[Bit_Len_PerSYM * s + k]; // bit k of the symbol = bit s*p+k
+		TX_MSG_SYM[s] = sym;
+	}
+	return 0;
+}
+
+// generator polynomials of Comm.cpp:513-533 as tap lists (G[0] and G[L] are always set)
+static void crc_taps(int len, int type24, int G[25])
+{
+	for (int i = 0; i < 25; i++) G[i] = 0;
+	if (len == 8) { const int t[] = {0, 1, 3, 4, 7, 8}; for (int x : t) G[x] = 1; }
+	else if (len == 16) { const int t[] = {0, 5, 12, 16}; for (int x : t) G[x] = 1; }
+	else if (len == 24 && !type24) { const int t[] = {0, 1, 3, 4, 5, 6, 7, 10, 11, 14, 17, 18, 23, 24}; for (int x : t) G[x] = 1; }
+	else if (len == 24) { const int t[] = {0, 1, 5, 6, 23, 24}; for (int x : t) G[x] = 1; }
+}
+
+void CComm::CRCEncode(int *out, const int *in, int n, int len, int type24) // Comm.cpp:506-561
+{
+	if (in != out) memcpy(out, in, sizeof(int) * n);
+	if (len == 0) return;
+	int G[25], reg[24] = {0};
+	crc_taps(len, type24, G);
+	for (int i = 0; i < n; i++) {
+		const int fb = reg[len - 1] ^ in[i];
+		for (int j = len - 1; j > 0; j--) reg[j] = reg[j - 1] ^ (G[j] && fb);
+		reg[0] = fb;
+	}
+	for (int i = 0; i < len; i++) out[n + i] = reg[len - 1 - i];
+}
+
+int CComm::CrcCheck(const int *in, int n, int len, int type24) // Comm.cpp:564-636
+{
+	if (len == 0) return 1;
+	int G[25], reg[24] = {0}, ones = 0;
+	crc_taps(len, type24, G);
+	for (int i = 0; i < n; i++) {
+		const int fb = reg[len - 1];
+		for (int j = len - 1; j > 0; j--) reg[j] = reg[j - 1] ^ (G[j] && fb);
+		reg[0] = fb ^ in[i];
+		ones += in[i];
+	}
+	int rem = 0;
+	for (int i = 0; i < len; i++) rem += reg[i];
+	return (rem == 0 && ones != 0) ? 1 : 0; // an all-zero word does not count as a CRC pass
+}
+
+int CComm::Encode() // Comm.cpp:255-289
+{
+	if (randomMsg) NBLDPC->Encode(TX_MSG_SYM.data(), TX_CODE_SYM.data());
+	else std::fill(TX_CODE_SYM.begin(), TX_CODE_SYM.end(), 0);
+	for (int s = 0; s < CODE_SYM_LEN; s++)
+		for (int k = 0; k < Bit_Len_PerSYM; k++) TX_CODE_BIT[s * Bit_Len_PerSYM + k] = (TX_CODE_SYM[s] >> k) & 1; // LSB first
+	for (int b = 0; b < MSG_BIT_LEN; b++) TX_MSG_BIT[b] = TX_CODE_BIT[b];
+	return 0;
+}
+
+int CComm::Puncture() // Comm.cpp:290-308
+{
+	int pi = 0, mb = 0;
+	for (int b = 0; b < CODE_BIT_LEN; b++) {
+		if (PUN_BIT_LEN != 0 && pi < PUN_BIT_LEN && PUN_BIT[pi] == b) pi++;
+		else TX_MOD_BIT[mb++] = TX_CODE_BIT[b];
+	}
+	return 0;
+}
+
+int CComm::Modulate() // Comm.cpp:310-325: MSB first (the reverse of Encode's unpacking -- reproduced as is)
+{
+	for (int s = 0; s < MOD_SYM_LEN; s++) {
+		int idx = 0;
+		for (int k = 0; k < MOD_BIT_PER_SYM; k++) idx += TX_MOD_BIT[s * MOD_BIT_PER_SYM + k] << (MOD_BIT_PER_SYM - 1 - k);
+		TX_MOD_SYM[s] = CONSTELLATION[idx];
+	}
+	return 0;
+}
+
+int CComm::Channel_AWGN() // Comm.cpp:328-337: real AND imaginary noise are drawn, also for BPSK
+{
+	for (int s = 0; s < MOD_SYM_LEN; s++) {
+		RX_MOD_SYM[s].Real = TX_MOD_SYM[s].Real + Rand.Rand_Norm(0, sigma_n);
+		RX_MOD_SYM[s].Image = TX_MOD_SYM[s].Image + Rand.Rand_Norm(0, sigma_n);
+	}
+	return 0;
+}
+
+int CComm::Demodulate() // Comm.cpp:340-407
+{
+	const int w = GFq - 1;
+	if (modOrder == 2) {
+		int pi = 0;
+		for (int b = 0; b < CODE_BIT_LEN; b++) {
+			if (PUN_BIT_LEN != 0 && pi < PUN_BIT_LEN && PUN_BIT[pi] == b) { pi++; RX_LLR_BIT[b] = 0; }
+			else RX_LLR_BIT[b] = -2 * RX_MOD_SYM[b - pi].Real / (sigma_n * sigma_n);
+		}
+		for (int s = 0; s < CODE_SYM_LEN; s++)
+			for (int q = 1; q < GFq; q++) {
+				double acc = 0;
+				for (int k = 0; k < Bit_Len_PerSYM; k++)
+					if ((q & (1 << k)) != 0) acc += RX_LLR_BIT[s * Bit_Len_PerSYM + k];
+				RX_LLR_SYM[(size_t)s * w + q - 1] = acc;
+			}
+	} else { // modOrder == GFq: one constellation point per code symbol
+		int pi = 0;
+		const CComplex &c0 = CONSTELLATION[0];
+		for (int s = 0; s < CODE_SYM_LEN; s++) {
+			if (PUN_SYM_LEN != 0 && pi < PUN_SYM_LEN && PUN_SYM[pi] == s) {
+				pi++;
+				for (int q = 1; q < GFq; q++) RX_LLR_SYM[(size_t)s * w + q - 1] = 0;
+			} else {
+				const CComplex &r = RX_MOD_SYM[s - pi];
+				for (int q = 1; q < GFq; q++) {
+					const CComplex &cq = CONSTELLATION[q];
+					RX_LLR_SYM[(size_t)s * w + q - 1] =
+					    ((2 * r.Real - c0.Real - cq.Real) * (cq.Real - c0.Real) + (2 * r.Image - c0.Image - cq.Image) * (cq.Image - c0.Image)) /
+					    (2 * sigma_n * sigma_n);
+				}
+			}
+		}
+	}
+	return 0;
+}
+
+int CComm::TakeDecoded(const int *decoded, bool converged) // Comm.cpp:421-443
+{
+	DecodeCorrect = converged;
+	for (int s = 0; s < CODE_SYM_LEN; s++) {
+		RX_DECODE_SYM[s] = decoded[s];
+		for (int k = 0; k < Bit_Len_PerSYM; k++) RX_DECODE_BIT[s * Bit_Len_PerSYM + k] = (decoded[s] >> k) & 1;
+	}
+	for (int s = 0; s < MSG_SYM_LEN; s++) RX_MSG_SYM[s] = RX_DECODE_SYM[s];
+	for (int b = 0; b < MSG_BIT_LEN; b++) RX_MSG_BIT[b] = RX_DECODE_BIT[b];
+	return 0;
+}
+
+int CComm::Err(CSimulation &sim) // Comm.cpp:446-503
+{
+	double errSym = 0, errBit = 0;
+	for (int s = 0; s < MSG_SYM_LEN; s++) errSym += (TX_MSG_SYM[s] != RX_MSG_SYM[s]);
+	for (int b = 0; b < MSG_BIT_LEN; b++) errBit += (TX_MSG_BIT[b] != RX_MSG_BIT[b]);
+	const int crc_ok = CrcCheck(RX_MSG_BIT.data(), MSG_BIT_LEN, crcLen, 1);
+	sim.errSym += errSym;
+	sim.errBit += errBit;
+	sim.errFrame += (errSym != 0) ? 1 : 0;
+	if (crc_ok && errSym != 0) { sim.U_errSym += errSym; sim.U_errBit += errBit; sim.U_errFrame += 1; }
+	sim.SER = sim.errSym / (sim.simCycle * MSG_SYM_LEN * sim.parallel);
+	sim.BER = sim.errBit / (sim.simCycle * MSG_BIT_LEN * sim.parallel);
+	sim.FER = sim.errFrame / (sim.simCycle * sim.parallel);
+	sim.U_SER = sim.U_errSym / (sim.simCycle * MSG_SYM_LEN * sim.parallel);
+	sim.U_BER = sim.U_errBit / (sim.simCycle * MSG_BIT_LEN * sim.parallel);
+	sim.U_FER = sim.U_errFrame / (sim.simCycle * sim.parallel);
+	return 0;
+}

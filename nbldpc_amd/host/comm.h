@@ -1,0 +1,50 @@
+// nbldpc_amd/host/comm.h -- CComm: one lane of the reference's link chain (Comm.h / Comm.cpp), minus the decoder it used to
+// own: all lanes share one CNBLDPC (code parameters + encoder) and their frames are decoded together by the caller.
+//   FrontEnd()    = GenerateMessage, Encode, Puncture, Modulate, Channel_AWGN, Demodulate      (Comm.cpp:181-189)
+//   TakeDecoded() = the symbol/bit unpacking of CComm::Decode after NBLDPC.Decoding             (Comm.cpp:421-443)
+//   Err()         = error counting                                                              (Comm.cpp:446-503)
+#pragma once
+#include <string>
+#include <vector>
+#include "nbldpc_host.h"
+#include "rand.h"
+#include "simulation.h"
+
+struct CComplex { double Real = 0, Image = 0; };
+
+class CComm {
+public:
+	int GFq = 0, parallel_num = 1, Bit_Len_PerSYM = 0;
+	CNBLDPC *NBLDPC = nullptr;
+	CRand Rand;
+	int regPN[11] = {0};
+	int randomMsg = 0, crcLen = 0, crcLen_correct = 0;
+	int MSG_SYM_LEN = 0, MSG_BIT_LEN = 0, CODE_SYM_LEN = 0, CODE_BIT_LEN = 0, PUN_SYM_LEN = 0, PUN_BIT_LEN = 0;
+	int modOrder = 0, MOD_BIT_PER_SYM = 0, MOD_SYM_LEN = 0, MOD_BIT_LEN = 0;
+	double CodeRate = 0, sigma_n = 0;
+	std::vector<int> TX_MSG_BIT_beforeCRC, TX_MSG_BIT, TX_MSG_SYM, TX_CODE_SYM, TX_CODE_BIT, PUN_SYM, PUN_BIT, TX_MOD_BIT;
+	std::vector<int> RX_DECODE_SYM, RX_DECODE_BIT, RX_MSG_SYM, RX_MSG_BIT;
+	std::vector<CComplex> CONSTELLATION, TX_MOD_SYM, RX_MOD_SYM;
+	std::vector<double> RX_LLR_BIT;
+	std::vector<double> RX_LLR_SYM; // [CODE_SYM_LEN][GFq-1], row-major (the reference's double**)
+	bool DecodeCorrect = false;
+
+	bool Initial(CSimulation &sim, int parallel_order, CNBLDPC *shared);
+	double SetEbN0(CSimulation &sim, int parallel_order);
+	int FrontEnd();
+	int GenerateMessage();
+	int GenPN();
+	void CRCEncode(int *seqOut, const int *seqIn, int seqInLen, int crcLen, int crc24Type);
+	int CrcCheck(const int *seqIn, int seqInLen, int crcLen, int crc24Type);
+	int Encode();
+	int Puncture();
+	int Modulate();
+	int Channel_AWGN();
+	int Demodulate();
+	int TakeDecoded(const int *decoded_sym, bool converged);
+	int Err(CSimulation &sim);
+	std::string error;
+
+private:
+	void ResetSources(CSimulation &sim, int parallel_order);
+};
