@@ -130,8 +130,11 @@ def main():
     # bytes per codeword per iteration, w = 8 (FP64): L_ch read (N) + c2v read, v2c write, v2c read, c2v write (4E)
     bytes_iter = 8 * (q - 1) * (N + 4 * E)
     bytes_cw = 8 * (q - 1) * N + args.iters * bytes_iter + 4 * N + 4
-    # dominant kernel = EMS check node: reads E v2c vectors, writes E c2v vectors per codeword per launch
-    cn_bytes_launch = B * 8 * (q - 1) * 2 * E
+    # dominant kernel.  Fused iteration (one launch = variable-node + EMS check-node pass, the default for this code): its
+    # algorithmic bytes are the whole iteration's, 8(q-1)(N+4E) per codeword.  Unfused: the check-node kernel alone reads E v2c
+    # vectors and writes E c2v vectors, 8(q-1)2E per codeword.
+    fused = ms_vn == 0.0
+    cn_bytes_launch = B * (bytes_iter if fused else 8 * (q - 1) * 2 * E)
     cn_ms = ms_cn / max(n_cn, 1)
     cn_gbs = cn_bytes_launch / (cn_ms * 1e-3) / 1e9 if cn_ms > 0 else 0.0
     res = {
@@ -146,7 +149,7 @@ def main():
         "hbm_roofline_frac_whole_job": total_cw * bytes_cw / dt / 1e9 / (HBM_PEAK_GBS * world),
         "converged_frac": float(conv.float().mean().item()),
         "phase_ms_per_step": {"vn": ms_vn / args.steps, "syndrome": ms_syn / args.steps, "cn": ms_cn / args.steps},
-        "roofline": {"kernel": "cn_ems_kernel<256>", "bound": "hbm", "achieved": cn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"kernel": "cn_ems_q256_dc4_kernel<32, fused>" if fused else "cn_ems_q256_dc4_kernel<32>", "bound": "hbm", "achieved": cn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": cn_gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": cn_bytes_launch, "ms_per_launch": cn_ms},
     }
     if rank == 0 and world == 1 and args.cpu_sample != 0:
@@ -155,6 +158,7 @@ def main():
             threads = len(os.sched_getaffinity(0))
         except Exception:
             pass
+        threads = min(threads, 16)  # the GPU box gives a 1-GPU job a 16-CPU share
         n = args.cpu_sample if args.cpu_sample > 0 else threads
         cps, secs = cpu_baseline(nb, L[:n].cpu().numpy(), args.nm, args.nc, args.iters, threads)
         res["cpu_baseline"] = {"value": cps, "unit": "codewords/s", "cores": threads, "kind": "port",

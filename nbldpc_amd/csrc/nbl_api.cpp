@@ -28,7 +28,10 @@ struct nbl_decoder {
 	hipStream_t stream = nullptr;
 	bool record_state = false;
 	bool all_dc4 = false;       // every check has degree 4
-	bool force_generic = false; // debug: always use the generic kernels
+	bool all_dv2 = false;       // every variable has degree 2
+	double *c2v_alt = nullptr;  // second c2v buffer of the fused EMS iteration (flooding schedule -> double buffer)
+	const double *last_c2v = nullptr;
+	int force_generic = 0;      // debug: 1 = always the generic kernels, 2 = specialised kernels but no VN/CN fusion
 	bool profiling = false;
 	hipEvent_t ev[2] = {nullptr, nullptr};
 	std::vector<hipEvent_t> pev; // per-launch events (profiling only)
@@ -66,7 +69,8 @@ template <typename T> static nbl_status upload(nbl_decoder *d, const std::vector
 
 static void free_workspace(nbl_decoder *d)
 {
-	void *ptrs[] = {d->w.Lch, d->w.v2c, d->w.c2v, d->w.post, d->w.dec, d->w.out, d->w.iters, d->w.done, d->d_Lin, d->d_conv8};
+	void *ptrs[] = {d->w.Lch, d->w.v2c, d->w.c2v, d->w.post, d->w.dec, d->w.out, d->w.iters, d->w.done, d->d_Lin, d->d_conv8, d->c2v_alt};
+	d->c2v_alt = nullptr;
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	d->w.Lch = d->w.v2c = d->w.c2v = d->w.post = nullptr;
@@ -76,6 +80,12 @@ static void free_workspace(nbl_decoder *d)
 	d->d_conv8 = nullptr;
 	d->cap = 0;
 	d->ws_bytes = 0;
+}
+
+// EMS on a (2,4)-regular GF(256) code with nc >= 3 and nm in {8,16,32}: the whole iteration is one fused launch
+static bool fused_shape(const nbl_decoder *d)
+{
+	return d->prm.method == NBL_METHOD_EMS && d->all_dv2 && nbl_ems256_applicable(d->g, d->all_dc4, d->prm.ems_nm, d->prm.ems_nc);
 }
 
 static nbl_status ensure_workspace(nbl_decoder *d, int B)
@@ -89,6 +99,7 @@ static nbl_status ensure_workspace(nbl_decoder *d, int B)
 	HIP_TRY(d, alloc((void **)&d->w.Lch, (size_t)cap * N * q * 8));
 	HIP_TRY(d, alloc((void **)&d->w.v2c, (size_t)cap * E * q * 8));
 	HIP_TRY(d, alloc((void **)&d->w.c2v, (size_t)cap * E * q * 8));
+	if (fused_shape(d)) HIP_TRY(d, alloc((void **)&d->c2v_alt, (size_t)cap * E * q * 8));
 	if (d->record_state) HIP_TRY(d, alloc((void **)&d->w.post, (size_t)cap * N * q * 8));
 	HIP_TRY(d, alloc((void **)&d->w.dec, (size_t)cap * N * 4));
 	HIP_TRY(d, alloc((void **)&d->w.out, (size_t)cap * N * 4));
@@ -202,6 +213,8 @@ extern "C" nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_m
 	d->d_e2c_map = (int *)d->g.v_cpos;
 	d->all_dc4 = true;
 	for (int m = 0; m < M; m++) d->all_dc4 = d->all_dc4 && (code->chk_deg[m] == 4);
+	d->all_dv2 = true;
+	for (int n = 0; n < N; n++) d->all_dv2 = d->all_dv2 && (code->var_deg[n] == 2);
 	void *cnt = nullptr;
 	if (hipMalloc(&cnt, 16) != hipSuccess) return fail_create(d, NBL_ERR_NOMEM, "hipMalloc failed");
 	d->graph_allocs.push_back(cnt);
@@ -237,7 +250,7 @@ extern "C" nbl_status nbl_set_profiling(nbl_decoder *d, int32_t on)
 extern "C" nbl_status nbl_debug_force_generic(nbl_decoder *d, int32_t on)
 {
 	if (!d) return NBL_ERR_ARG;
-	d->force_generic = on != 0;
+	d->force_generic = on;
 	return NBL_OK;
 }
 
@@ -281,7 +294,7 @@ static nbl_status launch_cn(nbl_decoder *d, const NblRun &r, hipStream_t st)
 {
 	switch (d->prm.method) {
 	case NBL_METHOD_EMS:
-		if (!d->force_generic && nbl_ems256_applicable(d->g, d->all_dc4, r.nm, r.nc)) HIP_TRY(d, nbl_launch_cn_ems256(d->g, d->w, r, st));
+		if (d->force_generic != 1 && nbl_ems256_applicable(d->g, d->all_dc4, r.nm, r.nc)) HIP_TRY(d, nbl_launch_cn_ems256(d->g, d->w, r, false, st));
 		else HIP_TRY(d, nbl_launch_cn_ems(d->g, d->w, r, st));
 		break;
 	case NBL_METHOD_TEMS: HIP_TRY(d, nbl_launch_cn_tems(d->g, d->w, r, st)); break;
@@ -316,8 +329,32 @@ static nbl_status run_iterations(nbl_decoder *d, const double *d_Lin, int B, hip
 	HIP_TRY(d, mark(3));
 	HIP_TRY(d, nbl_launch_init(d_Lin, d->g, d->w, B, damp ? 1 : 0, st));
 	HIP_TRY(d, mark(3));
+	const bool fused = fused_shape(d) && d->force_generic == 0 && d->c2v_alt;
+	double *const bufA = d->w.c2v, *const bufB = d->c2v_alt;
+	d->last_c2v = bufA;
 	for (int it = 1; it <= p.max_iter; it++) {
 		r.iter = it;
+		if (fused) {
+			// one launch = variable-node pass + EMS check-node pass; c2v ping-pongs between the two buffers
+			NblWork wf = d->w;
+			wf.c2v_prev = (it & 1) ? bufA : bufB;
+			wf.c2v = (it & 1) ? bufB : bufA;
+			wf.store_v2c = d->record_state ? 1 : 0;
+			HIP_TRY(d, nbl_launch_cn_ems256(d->g, wf, r, true, st));
+			HIP_TRY(d, mark(2));
+			d->launches[2]++;
+			d->last_c2v = wf.c2v;
+			HIP_TRY(d, nbl_launch_syn(d->g, d->w, r, st));
+			HIP_TRY(d, mark(1));
+			d->launches[1]++;
+			if (!p.fixed_iters && p.poll_every > 0 && (it % p.poll_every) == 0) {
+				int n_done = 0;
+				HIP_TRY(d, hipMemcpyAsync(&n_done, d->w.n_done, sizeof(int), hipMemcpyDeviceToHost, st));
+				HIP_TRY(d, hipStreamSynchronize(st));
+				if (n_done >= B) break;
+			}
+			continue;
+		}
 		HIP_TRY(d, nbl_launch_vn(d->g, d->w, r, damp, st));
 		HIP_TRY(d, mark(0));
 		HIP_TRY(d, nbl_launch_syn(d->g, d->w, r, st));
@@ -402,7 +439,7 @@ extern "C" nbl_status nbl_read_state(nbl_decoder *d, int32_t b, double *post, do
 		else rc = grab(d->w.post + (size_t)b * N * q, nullptr, N, post);
 	}
 	if (!rc && v2c) rc = grab(d->w.v2c + (size_t)b * E * q, nullptr, E, v2c);
-	if (!rc && c2v) rc = grab(d->w.c2v + (size_t)b * E * q, d->d_e2c_map, E, c2v);
+	if (!rc && c2v) rc = grab((d->last_c2v ? d->last_c2v : d->w.c2v) + (size_t)b * E * q, d->d_e2c_map, E, c2v);
 	(void)hipFree(tmp);
 	return rc;
 }

@@ -192,7 +192,11 @@ __device__ __forceinline__ void finish_members(SelState &s, int nm, uint64_t (&m
 
 } // namespace
 
-template <int NM>
+// FUSED = true: one launch is a whole flooding iteration for dv = 2 codes.  The variable-node work of the reference
+// (a-posteriori sum L_ch + c2v_0 + c2v_1 in that order, hard decision, v2c = L_post - c2v, NBLDPC.cpp:808-823, 848-857) is
+// recomputed per edge from the previous iteration's c2v, so v2c never touches HBM; the wave that holds a variable's FIRST
+// edge writes its hard decision.  c2v is double-buffered (w.c2v_prev -> w.c2v) because the schedule is flooding.
+template <int NM, bool FUSED>
 __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	constexpr int LOGNM = (NM == 8) ? 3 : (NM == 16) ? 4 : 5;
@@ -221,15 +225,60 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	double v[4][4];
 	int t[4][4];
 	int hcoef[4];
+	if (!FUSED) {
 #pragma unroll
-	for (int j = 0; j < 4; j++) {
-		const double2 *src = (const double2 *)(V + (size_t)g.c_epos[c0 + j] * Q);
-		double2 d0 = src[lane], d1 = src[64 + lane];
-		v[j][0] = (lane == 0) ? 0.0 : d0.x;
-		v[j][1] = d0.y;
-		v[j][2] = d1.x;
-		v[j][3] = d1.y;
-		hcoef[j] = g.c_h[c0 + j];
+		for (int j = 0; j < 4; j++) {
+			const double2 *src = (const double2 *)(V + (size_t)g.c_epos[c0 + j] * Q);
+			double2 d0 = src[lane], d1 = src[64 + lane];
+			v[j][0] = (lane == 0) ? 0.0 : d0.x;
+			v[j][1] = d0.y;
+			v[j][2] = d1.x;
+			v[j][3] = d1.y;
+			hcoef[j] = g.c_h[c0 + j];
+		}
+	} else {
+		const double *Cp = w.c2v_prev + (size_t)b * g.E * Q;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const int n = g.c_var[c0 + j], e = g.c_epos[c0 + j], e0 = g.voff[n];
+			const int cpA = g.v_cpos[e0], cpB = g.v_cpos[e0 + 1];
+			const double2 *pl = (const double2 *)(w.Lch + ((size_t)b * g.N + n) * Q);
+			const double2 *pa = (const double2 *)(Cp + (size_t)cpA * Q);
+			const double2 *pb = (const double2 *)(Cp + (size_t)cpB * Q);
+			const double2 l0 = pl[lane], l1 = pl[64 + lane], a0 = pa[lane], a1 = pa[64 + lane], b0 = pb[lane], b1 = pb[64 + lane];
+			double post[4] = {(l0.x + a0.x) + b0.x, (l0.y + a0.y) + b0.y, (l1.x + a1.x) + b1.x, (l1.y + a1.y) + b1.y};
+			const bool ownA = (e == e0); // this check is the variable's first edge
+			v[j][0] = post[0] - (ownA ? a0.x : b0.x);
+			v[j][1] = post[1] - (ownA ? a0.y : b0.y);
+			v[j][2] = post[2] - (ownA ? a1.x : b1.x);
+			v[j][3] = post[3] - (ownA ? a1.y : b1.y);
+			if (lane == 0) v[j][0] = 0.0;
+			hcoef[j] = g.c_h[c0 + j];
+			if (ownA) {
+				// hard decision (DecideLLRVector :1542-1562): lowest symbol among the maxima, 0 unless the maximum is positive
+				if (lane == 0) post[0] = 0.0;
+				const double pm = wave_max_f64(dmax(dmax(post[0], post[1]), dmax(post[2], post[3])));
+				int cand = 0x7fffffff;
+#pragma unroll
+				for (int i = 3; i >= 0; i--) cand = (post[i] == pm) ? sym_of(lane, i) : cand;
+				const int arg = -wave_max_i32(-cand);
+				if (lane == 0) w.dec[(size_t)b * g.N + n] = (pm > 0.0) ? arg : 0;
+				if (w.post) {
+					double2 *pp = (double2 *)(w.post + ((size_t)b * g.N + n) * Q);
+					double2 p01, p23;
+					p01.x = post[0]; p01.y = post[1]; p23.x = post[2]; p23.y = post[3];
+					pp[lane] = p01;
+					pp[64 + lane] = p23;
+				}
+			}
+			if (w.store_v2c) {
+				double2 *pv = (double2 *)(w.v2c + ((size_t)b * g.E + e) * Q);
+				double2 v01, v23;
+				v01.x = v[j][0]; v01.y = v[j][1]; v23.x = v[j][2]; v23.y = v[j][3];
+				pv[lane] = v01;
+				pv[64 + lane] = v23;
+			}
+		}
 	}
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
@@ -516,15 +565,24 @@ bool nbl_ems256_applicable(const NblGraphDev &g, bool all_dc4, int nm, int nc)
 
 size_t nbl_ems256_lds_bytes(int nm) { return 2 * Q * 8 + (size_t)4 * nm * 16 + (size_t)4 * (nm + 8) * 16 + 16; }
 
-hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
+hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 {
 	dim3 grid((unsigned)((long long)r.B * g.M)), block(64);
 	const size_t lds = nbl_ems256_lds_bytes(r.nm);
-	switch (r.nm) {
-	case 8: cn_ems_q256_dc4_kernel<8><<<grid, block, lds, st>>>(g, w, r); break;
-	case 16: cn_ems_q256_dc4_kernel<16><<<grid, block, lds, st>>>(g, w, r); break;
-	case 32: cn_ems_q256_dc4_kernel<32><<<grid, block, lds, st>>>(g, w, r); break;
-	default: return hipErrorInvalidValue;
+	if (fused) {
+		switch (r.nm) {
+		case 8: cn_ems_q256_dc4_kernel<8, true><<<grid, block, lds, st>>>(g, w, r); break;
+		case 16: cn_ems_q256_dc4_kernel<16, true><<<grid, block, lds, st>>>(g, w, r); break;
+		case 32: cn_ems_q256_dc4_kernel<32, true><<<grid, block, lds, st>>>(g, w, r); break;
+		default: return hipErrorInvalidValue;
+		}
+	} else {
+		switch (r.nm) {
+		case 8: cn_ems_q256_dc4_kernel<8, false><<<grid, block, lds, st>>>(g, w, r); break;
+		case 16: cn_ems_q256_dc4_kernel<16, false><<<grid, block, lds, st>>>(g, w, r); break;
+		case 32: cn_ems_q256_dc4_kernel<32, false><<<grid, block, lds, st>>>(g, w, r); break;
+		default: return hipErrorInvalidValue;
+		}
 	}
 	return hipGetLastError();
 }

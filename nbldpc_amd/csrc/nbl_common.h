@@ -28,6 +28,8 @@ struct NblGraphDev {
 
 struct NblWork {
 	double *Lch, *v2c, *c2v, *post; // post only when state recording is on
+	const double *c2v_prev;         // fused EMS iteration: c2v of the previous iteration (read), c2v = this iteration (written)
+	int store_v2c;                  // fused EMS iteration: also write v2c (state read-back only)
 	int *dec, *out, *iters;
 	uint8_t *done;
 	int *n_done;                    // device counter of converged codewords

@@ -14,7 +14,7 @@ int nbl_ems_layers(const NblGraphDev &g, int nc);
 // specialised EMS check node (nbl_cn_ems256.hip)
 bool nbl_ems256_applicable(const NblGraphDev &g, bool all_dc4, int nm, int nc);
 size_t nbl_ems256_lds_bytes(int nm);
-hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);
+hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st);
 
 // T-EMS and log-QSPA check nodes (nbl_cn_tems.hip, nbl_cn_bp.hip)
 hipError_t nbl_launch_cn_tems(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);

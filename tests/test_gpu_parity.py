@@ -22,7 +22,8 @@ TEMS_SETS = ["cfg4_tems_bds", "tems_gf16_dc5"]
 LLR_TOL = 1e-9
 
 
-def _force_generic(dec, on=True):
+def _force_generic(dec, on=1):
+    """0: default kernel choice; 1: generic kernels only; 2: specialised kernels without the fused iteration"""
     dec.lib.nbl_debug_force_generic.argtypes = [C.c_void_p, C.c_int32]
     assert dec.lib.nbl_debug_force_generic(dec.h, int(on)) == 0
 
@@ -33,7 +34,7 @@ def _oracle_decoder(oracle, meta, max_iter, fixed=0):
                           oracle.CANONICAL, fixed_iters=fixed, **decoder_kwargs(meta["profile"]))
 
 
-@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("generic", [0, 1, 2])
 @pytest.mark.parametrize("name", EMS_SETS + TEMS_SETS)
 def test_decisions_equal_reference(name, generic):
     if generic and name in TEMS_SETS:
@@ -51,7 +52,7 @@ def test_decisions_equal_reference(name, generic):
         assert np.all(iters[conv == 0] == int(it)) and np.all(iters[conv == 1] <= int(it))
 
 
-@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("generic", [0, 1, 2])
 @pytest.mark.parametrize("name", EMS_SETS + TEMS_SETS)
 def test_state_bit_exact_vs_oracle_and_close_to_reference(oracle, name, generic):
     if generic and name in TEMS_SETS:
@@ -152,7 +153,7 @@ def test_all_ties_and_erasures(oracle, codename, nm, nc):
     L[4] = rng.normal(0, 6, (N, q - 1))
     L[5, :, :] = 1.0                                   # all symbols tie at a positive value
     kw = dict(ems_nm=nm, ems_nc=nc, ems_factor=1.0, ems_offset=0.0)
-    for generic in (False, True):
+    for generic in (0, 1, 2):
         dec = nb.Decoder(code, nb.METHOD_EMS, 6, **kw)
         _force_generic(dec, generic)
         dec.record_state(True)
