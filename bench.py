@@ -47,7 +47,8 @@ def synth_llr(torch, code_q, N, B, ebn0_db, seed, device):
     return torch.matmul(bit_llr, mask.t()).contiguous()  # [B][N][q-1]
 
 
-def cpu_baseline(nb, L_host, nm, nc, max_iter, threads):
+def cpu_baseline_port(nb, L_host, nm, nc, max_iter, threads):
+    """The oracle's LITERAL restatement of the reference EMS (same operation order incl. the DFS residue), one decoder per thread."""
     import pyoracle as po
     po.build()
     N, M, q, ev, ec, eh = nb.datafiles.code_edges(CODE)
@@ -57,7 +58,59 @@ def cpu_baseline(nb, L_host, nm, nc, max_iter, threads):
     t0 = time.time()
     po.decode_batch(mk, L_host, nthreads=threads)
     dt = time.time() - t0
-    return L_host.shape[0] / dt, dt
+    return {"value": L_host.shape[0] / dt, "unit": "codewords/s", "cores": threads, "kind": "port",
+            "sample": f"{L_host.shape[0]} codewords of the same batch, {max_iter} fixed iterations, oracle literal restatement of the "
+                      f"reference EMS (gcc -O2), {dt:.1f} s wall"}
+
+
+def cpu_baseline_reference(nb, nm, nc, max_iter, threads, frames=2):
+    """The COMPILED REFERENCE itself (oracle/_ref/ref_driver_O2, built in the build container from the unmodified sources; the
+    binary travels, the sources do not), one process per core like the reference's one CNBLDPC per lane.  The reference has no
+    fixed-iteration mode, so it is run at Eb/N0 = -3 dB where every frame fails and all `max_iter` iterations execute."""
+    import subprocess
+    import tempfile
+    from profiles import profile_text
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver_O2")
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="nbl_cpu_")
+    nb.datafiles.materialise(tmp, 256, CODE, "BPSK")
+    procs = []
+    t0 = time.time()
+    for k in range(threads):
+        prof = os.path.join(tmp, f"p{k}.txt")
+        with open(prof, "w") as f:
+            f.write(profile_text(gfq=256, code=CODE + ".txt", method=2, max_iter=max_iter, parallel=1, ems_nm=nm, ems_nc=nc,
+                                 snr_begin=-3.0, snr_stop=-3.0, constellation="BPSK.txt", random_msg=1, min_err_frame=-1,
+                                 min_sim_cycle=frames - 1, seed=173 + k))
+        procs.append(subprocess.Popen([exe, "fer", prof], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+    outs = [p.communicate()[0] for p in procs]
+    dt = time.time() - t0
+    done = 0
+    for o in outs:
+        for line in o.splitlines():
+            if line.startswith("{"):
+                r = json.loads(line)
+                if r["errFrame"] != r["frames"]:
+                    return None  # a frame converged early: not a fixed-iteration measurement
+                done += int(r["frames"])
+    if done == 0:
+        return None
+    return {"value": done / dt, "unit": "codewords/s", "cores": threads, "kind": "reference",
+            "sample": f"{done} codewords ({threads} processes x {frames}), compiled reference (g++ -O2) EMS nm={nm} nc={nc}, Eb/N0 -3 dB so "
+                      f"all {max_iter} iterations run, {dt:.1f} s wall"}
+
+
+def pmc_traffic(fused, B):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_summary.json: FETCH_SIZE and
+    WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md), scaled from the profiled batch of 16384."""
+    path = os.path.join(ROOT, "profiles", "r01_summary.json")
+    if not fused or not os.path.exists(path):
+        return None
+    for name, v in json.load(open(path)).get("hbm_pmc", {}).items():
+        if "cn_ems_q256_dc4_kernel<32, true>" in name:
+            return v["hbm_bytes_per_launch_corrected"] * B / 16384.0
+    return None
 
 
 def main():
@@ -150,7 +203,7 @@ def main():
         "converged_frac": float(conv.float().mean().item()),
         "phase_ms_per_step": {"vn": ms_vn / args.steps, "syndrome": ms_syn / args.steps, "cn": ms_cn / args.steps},
         "roofline": {"kernel": "cn_ems_q256_dc4_kernel<32, fused>" if fused else "cn_ems_q256_dc4_kernel<32>", "bound": "hbm", "achieved": cn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": cn_gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": cn_bytes_launch, "ms_per_launch": cn_ms},
+                     "frac": cn_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(fused, B), "bytes_per_launch": cn_bytes_launch, "ms_per_launch": cn_ms},
     }
     if rank == 0 and world == 1 and args.cpu_sample != 0:
         threads = os.cpu_count() or 1
@@ -159,11 +212,11 @@ def main():
         except Exception:
             pass
         threads = min(threads, 16)  # the GPU box gives a 1-GPU job a 16-CPU share
-        n = args.cpu_sample if args.cpu_sample > 0 else threads
-        cps, secs = cpu_baseline(nb, L[:n].cpu().numpy(), args.nm, args.nc, args.iters, threads)
-        res["cpu_baseline"] = {"value": cps, "unit": "codewords/s", "cores": threads, "kind": "port",
-                               "sample": f"{n} codewords of the same batch, {args.iters} fixed iterations, oracle literal "
-                                         f"restatement of the reference EMS (gcc -O2), {secs:.1f} s wall"}
+        n = args.cpu_sample if args.cpu_sample > 0 else 4 * threads
+        ref = cpu_baseline_reference(nb, args.nm, args.nc, args.iters, threads)
+        port = cpu_baseline_port(nb, L[:n].cpu().numpy(), args.nm, args.nc, args.iters, threads)
+        res["cpu_baseline"] = ref if ref is not None else port
+        res["cpu_baseline_port"] = port
     if rank == 0:
         print(json.dumps(res))
     dec.close()
