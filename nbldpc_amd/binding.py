@@ -50,6 +50,13 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(f"{LIB_PATH} is missing: build it with `make -C nbldpc_amd/csrc` "
                                     "(or python -c 'import __graft_entry__ as g; g.build()')")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.  If torch is going to be used in this process
+        # (bench.py, tests) it must be loaded BEFORE our library so that both resolve to the same runtime instance; loading
+        # ours first makes a later torch.cuda initialisation fail with "No HIP GPUs are available".
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         L.nbl_abi_version.restype = C.c_int32
         L.nbl_create.restype = C.c_int

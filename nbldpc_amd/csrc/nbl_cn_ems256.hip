@@ -317,25 +317,32 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	bool mem[4][4];
 	{
 		int bk[4][4];
-		int *H = (int *)U; // [64 buckets][4 edges]
-		int4 z4 = {0, 0, 0, 0};
-		((int4 *)H)[lane] = z4;
+		int *H = (int *)U; // [256 buckets][4 edges] (spans U and P); lane l reads buckets 4l .. 4l+3
+		{
+			int4 z4 = {0, 0, 0, 0};
+#pragma unroll
+			for (int i = 0; i < 4; i++) ((int4 *)H)[lane * 4 + i] = z4;
+		}
 		__syncthreads();
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const double range = mtop[j] - lmin[j];
-			const double scale = range > 0.0 ? 64.0 / range : 0.0;
+			const double scale = range > 0.0 ? 256.0 / range : 0.0;
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
 				const double d = (mtop[j] - v[j][i]) * scale;
-				int bi = (int)dmin(d, 63.0);
-				bk[j][i] = (v[j][i] >= lmin[j]) ? bi : 64;
-				if (bk[j][i] < 64) atomicAdd(&H[bk[j][i] * 4 + j], 1);
+				int bi = (int)dmin(d, 255.0);
+				bk[j][i] = (v[j][i] >= lmin[j]) ? bi : 256;
+				if (bk[j][i] < 256) atomicAdd(&H[bk[j][i] * 4 + j], 1);
 			}
 		}
 		__syncthreads();
-		int4 cnt4 = ((int4 *)H)[lane];
-		const int cnt[4] = {cnt4.x, cnt4.y, cnt4.z, cnt4.w};
+		int hc[4][4]; // [bucket slot of this lane][edge]
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int4 h4 = ((int4 *)H)[lane * 4 + i];
+			hc[i][0] = h4.x; hc[i][1] = h4.y; hc[i][2] = h4.z; hc[i][3] = h4.w;
+		}
 		STAMP(2);
 #pragma unroll
 		for (int jp = 0; jp < 4; jp += 2) {
@@ -343,9 +350,14 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 #pragma unroll
 			for (int u = 0; u < 2; u++) {
 				const int j = jp + u;
-				const int cum = wave_scan_add(cnt[j]);
+				const int tot = hc[0][j] + hc[1][j] + hc[2][j] + hc[3][j];
+				const int cum = wave_scan_add(tot);
 				const uint64_t reach = __ballot(cum >= NM);
-				const int bstar = reach ? __builtin_ctzll(reach) : 63;
+				const int lstar = reach ? __builtin_ctzll(reach) : 63;
+				// every lane works out which of its four buckets would be the cut; the cut lane's answer is read back
+				const int pre = cum - tot, s0 = pre + hc[0][j], s1 = s0 + hc[1][j], s2 = s1 + hc[2][j];
+				const int bsel = (s0 >= NM) ? 0 : (s1 >= NM) ? 1 : (s2 >= NM) ? 2 : 3;
+				const int bstar = 4 * lstar + __builtin_amdgcn_readlane(bsel, lstar);
 #pragma unroll
 				for (int i = 0; i < 4; i++) {
 					ss[u].cand[i] = __ballot(bk[j][i] == bstar);

@@ -18,6 +18,10 @@ def load():
     if _lib is None:
         if not os.path.exists(HOST_LIB):
             raise FileNotFoundError(f"{HOST_LIB} is missing: make -C nbldpc_amd/host")
+        try:
+            import torch  # noqa: F401  (same reason as in binding.load_library: one HIP runtime per process)
+        except Exception:
+            pass
         L = C.CDLL(HOST_LIB)
         L.nblh_frontend.argtypes = [C.c_char_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         L.nblh_simulate.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int]
