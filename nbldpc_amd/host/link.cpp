@@ -1,7 +1,9 @@
 // nbldpc_amd/host/link.cpp -- see link.h.
 #include "link.h"
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <thread>
 
 bool CLink::Initial(const std::string &profile, int device)
 {
@@ -30,9 +32,23 @@ bool CLink::Cycle()
 {
 	const int P = sim.parallel;
 	const size_t per = (size_t)code.CodeLen * (code.GFq - 1);
-	for (int i = 0; i < P; i++) {
-		lanes[i]->FrontEnd();
-		memcpy(&L_batch[per * i], lanes[i]->RX_LLR_SYM.data(), sizeof(double) * per);
+	// lanes own their RNG / PN / buffers, so their front-ends run in parallel exactly like the reference's parallel_for
+	// (main.cpp:46); results do not depend on the thread count
+	auto work = [&](int lo, int hi) {
+		for (int i = lo; i < hi; i++) {
+			lanes[i]->FrontEnd();
+			memcpy(&L_batch[per * i], lanes[i]->RX_LLR_SYM.data(), sizeof(double) * per);
+		}
+	};
+	int T = 1;
+	if (const char *e = getenv("NBL_HOST_THREADS")) T = atoi(e);
+	else { T = (int)std::thread::hardware_concurrency(); if (T > 16) T = 16; }
+	if (T > P) T = P;
+	if (T <= 1) work(0, P);
+	else {
+		std::vector<std::thread> th;
+		for (int t = 0; t < T; t++) th.emplace_back(work, (int)((long long)P * t / T), (int)((long long)P * (t + 1) / T));
+		for (auto &x : th) x.join();
 	}
 	if (code.DecodingBatch(L_batch.data(), P, out_batch.data(), conv.data(), iters.data()) != 0) { error = code.LastError(); return false; }
 	for (int i = 0; i < P; i++) {

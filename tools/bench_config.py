@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Throughput of the other BASELINE.json configurations (parity-test cases, not the headline bench line).
+
+usage: python tools/bench_config.py cfg2|cfg3|cfg4|cfg5 [batch] [steps]
+Prints one JSON line: codewords/s at fixed iterations with HBM-resident inputs, plus the algorithmic-bytes roofline fraction
+(8(q-1)[N + I(N + 4E + D E)] + 4N + 4 bytes per codeword, D = 1 for BP / T-EMS).
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import nbldpc_amd as nb  # noqa: E402
+
+CFG = {
+    "cfg2": dict(code="divsalar.UNBLDPC.128.64.GF.256", method=nb.METHOD_EMS, iters=50, batch=4096, kw=dict(ems_nm=16, ems_nc=3), D=0, ebn0=2.0, mod="bpsk"),
+    "cfg3": dict(code="divsalar.UNBLDPC.512.256.GF.256", method=nb.METHOD_EMS, iters=50, batch=16384, kw=dict(ems_nm=32, ems_nc=3), D=0, ebn0=1.0, mod="bpsk"),
+    "cfg4": dict(code="BDS.576.288.GF.64", method=nb.METHOD_TEMS, iters=50, batch=8192, kw=dict(tems_nr=2, tems_nc=3), D=1, ebn0=3.0, mod="qam"),
+    "cfg5": dict(code="divsalar.CNBLDPC.512.256.GF.256", method=nb.METHOD_BP, iters=100, batch=1024, kw=dict(), D=1, ebn0=10.0, mod="qam"),
+}
+
+
+def synth(code, B, ebn0, mod, dev):
+    q, N = code.q, code.N
+    p = q.bit_length() - 1
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(173)
+    if mod == "bpsk":
+        sigma = 1.0 / np.sqrt(2 * 1 * 0.5 * 10 ** (ebn0 / 10.0))
+        rx = 1.0 + sigma * torch.randn((B, N, p), dtype=torch.float64, device=dev, generator=gen)
+        bit = -2.0 * rx / sigma ** 2
+        a = torch.arange(1, q, device=dev)
+        mask = ((a[:, None] >> torch.arange(p, device=dev)[None, :]) & 1).to(torch.float64)
+        return torch.matmul(bit, mask.t()).contiguous()
+    # q-ary QAM, all-zero codeword: LLR(a) = ((2r - c0 - ca).(ca - c0)) / (2 sigma^2)   (Comm.cpp:394-395)
+    name = {64: "GRAY_64QAM", 256: "GRAY_256QAM"}[q]
+    pts = sorted(nb.datafiles.constellations()[name])
+    c = torch.tensor([[x[1], x[2]] for x in pts], dtype=torch.float64, device=dev)
+    sigma = 1.0 / np.sqrt(2 * p * 0.5 * 10 ** (ebn0 / 10.0))
+    r = c[0][None, None, :] + sigma * torch.randn((B, N, 2), dtype=torch.float64, device=dev, generator=gen)
+    d = c[1:] - c[0]
+    return ((2 * r[:, :, None, :] - c[0] - c[1:]) * d).sum(-1) / (2 * sigma ** 2)
+
+
+def main():
+    name = sys.argv[1]
+    c = CFG[name]
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else c["batch"]
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    dev = torch.device("cuda", 0)
+    code = nb.Code(c["code"])
+    L = synth(code, B, c["ebn0"], c["mod"], dev).contiguous()
+    dec = nb.Decoder(code, c["method"], c["iters"], fixed_iters=1, max_batch=B, **c["kw"])
+    out = torch.zeros((B, code.N), dtype=torch.int32, device=dev)
+    conv = torch.zeros(B, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    dec.decode_device(L.data_ptr(), B, out.data_ptr(), conv.data_ptr(), None, st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dec.decode_device(L.data_ptr(), B, out.data_ptr(), conv.data_ptr(), None, st)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    q, N, E, I = code.q, code.N, code.E, c["iters"]
+    bytes_cw = 8 * (q - 1) * (N + I * (N + 4 * E + c["D"] * E)) + 4 * N + 4
+    cws = B * steps / dt
+    print(json.dumps({"config": name, "code": c["code"], "method": c["method"], "iters": I, "batch": B, "codewords_per_s": cws,
+                      "ms_per_batch": dt / steps * 1e3, "algorithmic_GBps": cws * bytes_cw / 1e9, "hbm_frac": cws * bytes_cw / 8e12,
+                      "converged_frac": float(conv.float().mean().item())}))
+
+
+if __name__ == "__main__":
+    main()
