@@ -214,8 +214,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 
 	double *U = (double *)smem;              // [256] check-domain copy of one input vector | histogram | S of one output
 	double *P = U + Q;                       // [256] pair convolution (U..P together: candidate buffer of the selection)
-	ListEnt *lst = (ListEnt *)(P + Q);       // [4][NM]   the nm best of every edge, contiguous (pair convolution)
-	ListEnt *lstp = lst + 4 * NM;            // [4][NMP]  same entries grouped by symbol bit 0 and padded (gather)
+	ListEnt *lstp = (ListEnt *)(P + Q);      // [4][NMP]  the nm best of every edge, grouped by symbol bit 0 and padded
 	int *misc = (int *)(lstp + 4 * NMP);     // [4] scratch counters
 
 	unsigned long long st_t0 = 0, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -228,7 +227,9 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 
 	// ---- load the four incoming vectors (two 16-byte loads each) and their check-domain symbols ------------------
 	double v[4][4];
-	int t[4][4];
+	unsigned tp[4]; // check-domain symbols h_j * a of the lane's four slots, packed one byte each (keeps 12 VGPRs free:
+	                // with 16 separate registers hipcc rematerialises the GF multiplication at every use)
+#define TSYM(j, i) ((int)((tp[j] >> (8 * (i))) & 255u))
 	int hcoef[4];
 	if (!FUSED) {
 #pragma unroll
@@ -289,8 +290,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	for (int j = 0; j < 4; j++) {
 		GfMulL mh;
 		mh.init(hcoef[j], g.poly, lane);
-#pragma unroll
-		for (int i = 0; i < 4; i++) t[j][i] = mh.at_slot(i);
+		tp[j] = (unsigned)mh.at_slot(0) | ((unsigned)mh.at_slot(1) << 8) | ((unsigned)mh.at_slot(2) << 16) | ((unsigned)mh.at_slot(3) << 24);
 	}
 	STAMP(0);
 
@@ -381,8 +381,8 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	}
 	STAMP(3);
 
-	// ---- compact the members into the two list images ---------------------------------------------------------------
-	int n0p[4], n1p[4];
+	// ---- compact the members into the padded list image: [even-symbol group | pad to 4 | odd-symbol group | pad to 4] ----
+	int n0[4], n0p[4], n1p[4];
 	__syncthreads();
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
@@ -390,35 +390,37 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		int c0n = 0;
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
-			g0[i] = __ballot(mem[j][i] && (t[j][i] & 1) == 0);
-			g1[i] = __ballot(mem[j][i] && (t[j][i] & 1) != 0);
+			const bool odd = (tp[j] >> (8 * i)) & 1u;
+			g0[i] = __ballot(mem[j][i] && !odd);
+			g1[i] = __ballot(mem[j][i] && odd);
 			c0n += __popcll(g0[i]);
 		}
-		const int n0 = c0n, n1 = NM - c0n;
-		n0p[j] = (n0 + 3) & ~3;
-		n1p[j] = (n1 + 3) & ~3;
-		// pads first (never win a max), members overwrite nothing of them
-		if (lane < 8) {
+		n0[j] = c0n;
+		n0p[j] = (c0n + 3) & ~3;
+		n1p[j] = (NM - c0n + 3) & ~3;
+		ListEnt *Lj = lstp + j * NMP;
+		if (lane < 8) { // pads (never win a max); member slots are disjoint from them
 			ListEnt pe;
 			pe.v = NBL_NEG_INF;
 			pe.t = 0;
 			pe.tt = 0;
-			const int pos = (lane < 4) ? n0 + lane : n0p[j] + n1 + (lane - 4);
-			const bool need = (lane < 4) ? (n0 + lane < n0p[j]) : (n1 + lane - 4 < n1p[j]);
-			if (need) lstp[j * NMP + pos] = pe;
+			const int n1 = NM - c0n;
+			const int pos = (lane < 4) ? c0n + lane : n0p[j] + n1 + (lane - 4);
+			const bool need = (lane < 4) ? (c0n + lane < n0p[j]) : (n1 + lane - 4 < n1p[j]);
+			if (need) Lj[pos] = pe;
 		}
-		int base0 = 0, base1 = 0;
+		int base0 = 0, base1 = n0p[j];
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
+			const int sym = TSYM(j, i);
+			const int pe_ = base0 + prefix_count(g0[i]), po_ = base1 + prefix_count(g1[i]);
+			const int pos = (sym & 1) ? po_ : pe_;
 			if (mem[j][i]) {
-				const bool ev = (t[j][i] & 1) == 0;
-				const int pg = ev ? base0 + prefix_count(g0[i]) : base1 + prefix_count(g1[i]);
 				ListEnt e;
 				e.v = v[j][i];
-				e.t = t[j][i];
-				e.tt = (t[j][i] & 0xFE) << 3;
-				lst[j * NM + (ev ? pg : n0 + pg)] = e;
-				lstp[j * NMP + (ev ? pg : n0p[j] + pg)] = e;
+				e.t = sym;
+				e.tt = (sym & 0xFE) << 3;
+				Lj[pos] = e;
 			}
 			base0 += __popcll(g0[i]);
 			base1 += __popcll(g1[i]);
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	for (int j = 0; j < 4; j++) {
 		__syncthreads();
 #pragma unroll
-		for (int i = 0; i < 4; i++) U[t[j][i]] = v[j][i];
+		for (int i = 0; i < 4; i++) U[TSYM(j, i)] = v[j][i];
 		__syncthreads();
 #pragma unroll
 		for (int x = 0; x < 4; x++) {
@@ -468,12 +470,15 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		ninf.y = NBL_NEG_INF;
 		((double2 *)P)[lane] = ninf;
 		((double2 *)P)[64 + lane] = ninf;
-		const ListEnt ea = lst[ja * NM + (lane & (NM - 1))];
+		// entry k of the contiguous member list lives at k (even group) or k - n0 + n0p (odd group) of the padded image
+		const int ka = lane & (NM - 1);
+		const ListEnt ea = lstp[ja * NMP + (ka < n0[ja] ? ka : ka - n0[ja] + n0p[ja])];
 		__syncthreads();
 		constexpr int PER = 64 >> LOGNM, ROUNDS = (NM << LOGNM) >> 6;
 #pragma unroll
 		for (int it = 0; it < ROUNDS; it++) {
-			const ListEnt eb = lst[jb * NM + it * PER + (lane >> LOGNM)];
+			const int kb = it * PER + (lane >> LOGNM);
+			const ListEnt eb = lstp[jb * NMP + (kb < n0[jb] ? kb : kb - n0[jb] + n0p[jb])];
 			__hip_atomic_fetch_max(&P[ea.t ^ eb.t], ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 		__syncthreads();
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		const double s0 = Sx[0];
 		double y[4];
 #pragma unroll
-		for (int i = 0; i < 4; i++) y[i] = shape_llr(Sx[t[x][i]] - s0, r.factor, r.offset);
+		for (int i = 0; i < 4; i++) y[i] = shape_llr(Sx[TSYM(x, i)] - s0, r.factor, r.offset);
 		if (lane == 0) y[0] = 0.0;
 		double2 o01, o23;
 		o01.x = y[0]; o01.y = y[1]; o23.x = y[2]; o23.y = y[3];
@@ -573,6 +578,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		atomicAdd(&w.stamps[15], 1ull);
 	}
 #undef STAMP
+#undef TSYM
 }
 
 bool nbl_ems256_applicable(const NblGraphDev &g, bool all_dc4, int nm, int nc)
@@ -580,7 +586,7 @@ bool nbl_ems256_applicable(const NblGraphDev &g, bool all_dc4, int nm, int nc)
 	return g.q == 256 && all_dc4 && nc >= 3 && (nm == 8 || nm == 16 || nm == 32);
 }
 
-size_t nbl_ems256_lds_bytes(int nm) { return 2 * Q * 8 + (size_t)4 * nm * 16 + (size_t)4 * (nm + 8) * 16 + 16; }
+size_t nbl_ems256_lds_bytes(int nm) { return 2 * Q * 8 + (size_t)4 * (nm + 8) * 16 + 16; }
 
 hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 {
