@@ -60,6 +60,11 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     dec.decode_device(L.data_ptr(), B, out.data_ptr(), conv.data_ptr(), None, st)
     torch.cuda.synchronize()
+    dec.profiling(True)
+    dec.decode_device(L.data_ptr(), B, out.data_ptr(), conv.data_ptr(), None, st)
+    torch.cuda.synchronize()
+    phase_ms, launches = dec.last_timing()
+    dec.profiling(False)
     t0 = time.perf_counter()
     for _ in range(steps):
         dec.decode_device(L.data_ptr(), B, out.data_ptr(), conv.data_ptr(), None, st)
@@ -70,7 +75,8 @@ def main():
     cws = B * steps / dt
     print(json.dumps({"config": name, "code": c["code"], "method": c["method"], "iters": I, "batch": B, "codewords_per_s": cws,
                       "ms_per_batch": dt / steps * 1e3, "algorithmic_GBps": cws * bytes_cw / 1e9, "hbm_frac": cws * bytes_cw / 8e12,
-                      "converged_frac": float(conv.float().mean().item())}))
+                      "converged_frac": float(conv.float().mean().item()),
+                      "phase_ms": {"vn": phase_ms[0], "syndrome": phase_ms[1], "cn": phase_ms[2]}, "launches": launches}))
 
 
 if __name__ == "__main__":
