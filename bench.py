@@ -69,7 +69,7 @@ def cpu_baseline_reference(nb, nm, nc, max_iter, threads, frames=2):
     fixed-iteration mode, so it is run at Eb/N0 = -3 dB where every frame fails and all `max_iter` iterations execute."""
     import subprocess
     import tempfile
-    from profiles import profile_text
+    from nbldpc_amd.profiles import profile_text
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver_O2")
     if not os.path.exists(exe):
         return None
@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--nc", type=int, default=3)
     ap.add_argument("--ebn0", type=float, default=1.0)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="codewords for the CPU baseline (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -135,7 +137,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.same_device:
+            local_rank = 0
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -173,7 +180,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

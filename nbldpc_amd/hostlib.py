@@ -42,9 +42,7 @@ def workdir(path):
 
 def prepare_workdir(path, profile_kwargs, code_name, constellation_name):
     """Lay out SRC/, the code file, the constellation file and NBLDPC.Profile.txt like the reference's working directory."""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(_HERE), "tools"))
-    from profiles import profile_text
+    from .profiles import profile_text
     kw = dict(profile_kwargs)
     datafiles.materialise(path, kw["gfq"], code_name, constellation_name)
     kw["code"] = code_name + ".txt"

@@ -2,7 +2,7 @@
 
 The reference parser (Simulation.cpp:58-107) identifies each value only by the number of label tokens
 in front of it, so the label words below are free text of our own choosing; the token counts are what
-matter.  Used by tools/make_golden.py (build container) and by the tests (to write profiles into tmp dirs).
+matter.  Used by tests/golden/make_golden.py (build container), the tests and bench.py (to write profiles into work dirs).
 """
 
 DEFAULTS = dict(

@@ -6,7 +6,7 @@
  *
  * Parity pin: `literal` modes reproduce the compiled reference (oracle/_ref, built from the unmodified
  * sources by oracle/Makefile) bit for bit on LLR state, hard decisions and return flags -- checked by
- * tests/test_oracle_golden.py against the tests/golden npz files generated with tools/make_golden.py.
+ * tests/test_oracle_golden.py against the tests/golden npz files generated with tests/golden/make_golden.py.
  * `canonical` modes define the residue-free value the HIP kernels compute.
  */
 #ifndef NBL_ORACLE_H

@@ -8,7 +8,7 @@
 //   CComm::GenerateMessage..Demodulate  /root/reference/Comm.cpp:194-407
 //   CNBLDPC::Decoding               /root/reference/NBLDPC.cpp:607
 // It exists only in the build container (the reference does not travel to the GPU box); its outputs are
-// packed into tests/golden/*.npz by tools/make_golden.py.
+// packed into tests/golden/*.npz by tests/golden/make_golden.py.
 //
 // usage (cwd must contain ./SRC/ with the GF tables, see oracle/Makefile):
 //   ref_driver dump <profile> <outdir> <EbN0> <frames> <iters,csv> <state_iters,csv>

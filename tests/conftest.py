@@ -25,8 +25,8 @@ def load_golden(name):
 
 
 def decoder_kwargs(profile):
-    """EMS / T-EMS parameters of a golden profile, with the defaults of tools/profiles.py."""
-    from profiles import DEFAULTS
+    """EMS / T-EMS parameters of a golden profile, with the defaults of nbldpc_amd/profiles.py."""
+    from nbldpc_amd.profiles import DEFAULTS
     p = dict(DEFAULTS)
     p.update(profile)
     return dict(ems_nm=p["ems_nm"], ems_nc=p["ems_nc"], ems_factor=p["ems_factor"], ems_offset=p["ems_offset"],

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/*.npz from the COMPILED REFERENCE (oracle/_ref, see oracle/Makefile `make ref`).
+"""Generate the tests/golden npz fixtures from the COMPILED REFERENCE (oracle/_ref, see oracle/Makefile `make ref`).
 
-Build-container only: needs /root/reference.  Each set is one profile (tools/profiles.py grammar) run through
+Build-container only: needs /root/reference.  Each set is one profile (nbldpc_amd/profiles.py grammar) run through
 oracle/ref_driver.cpp, which calls the unmodified CSimulation / CComm / CNBLDPC objects and dumps
   L_ch      [B][N][q-1]  channel LLRs produced by the reference's own link chain (frame-major, b = f*P + lane)
   tx_code   [B][N]       transmitted codeword symbols
@@ -9,7 +9,7 @@ oracle/ref_driver.cpp, which calls the unmodified CSimulation / CComm / CNBLDPC 
   st_post/st_v2c/st_c2v  message state after state_iters[k] iterations (frame 0; var-major edge order)
 plus FER anchor lines (fer mode).  Large state arrays are subsampled (`state_lanes`) to keep fixtures small.
 
-usage: python tools/make_golden.py [set ...]
+usage: python tests/golden/make_golden.py [set ...]
 """
 import json
 import os
@@ -22,9 +22,9 @@ import time
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(HERE)
-sys.path.insert(0, HERE)
-from profiles import profile_text  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from nbldpc_amd.profiles import profile_text  # noqa: E402
 
 REF = "/root/reference/"
 RUN = os.path.join(ROOT, "oracle", "_ref", "run")

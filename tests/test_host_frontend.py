@@ -43,7 +43,7 @@ def test_encoder_produces_codewords(tmp_path):
 
 def test_profile_grammar_is_positional(tmp_path):
     """Label words are free text; only their count matters (Simulation.cpp:58-107)."""
-    from profiles import profile_text
+    from nbldpc_amd.profiles import profile_text
     name = "divsalar.UNBLDPC.128.64.GF.16"
     hostlib.prepare_workdir(str(tmp_path), dict(gfq=16, code=name, method=2, ems_nm=8, constellation="BPSK", parallel=2, random_msg=1), name, "BPSK")
     a = hostlib.frontend(str(tmp_path), 2.0, 1, 32, 16, 16, 2)
