@@ -47,6 +47,20 @@ def synth_llr(torch, code_q, N, B, ebn0_db, seed, device):
     return torch.matmul(bit_llr, mask.t()).contiguous()  # [B][N][q-1]
 
 
+def harness_llr(nb, B, ebn0, seed, max_iter, nm, nc):
+    """Synthetic inputs produced by the harness itself, not random tensors: B lanes of the reference-compatible link
+    chain in nbldpc_amd/host (11-stage LFSR message -> CRC-8 -> systematic encode -> BPSK -> AWGN from the 3-LCG generator seeded
+    seed+lane -> bit LLRs -> symbol LLRs), bit-identical to what the reference's CComm produces (tests/test_host_frontend.py)."""
+    import tempfile
+    from nbldpc_amd import hostlib
+    tmp = tempfile.mkdtemp(prefix="nbl_bench_")
+    hostlib.prepare_workdir(tmp, dict(gfq=256, code=CODE, method=2, max_iter=max_iter, parallel=B, ems_nm=nm, ems_nc=nc,
+                                      constellation="BPSK", random_msg=1, seed=seed), CODE, "BPSK")
+    c = nb.datafiles.codes()[CODE]
+    L, tx, _, _ = hostlib.frontend(tmp, ebn0, 1, c["N"], c["N"] - c["M"], c["q"], B)
+    return L, tx
+
+
 def cpu_baseline_port(nb, L_host, nm, nc, max_iter, threads):
     """The oracle's LITERAL restatement of the reference EMS (same operation order incl. the DFS residue), one decoder per thread."""
     import pyoracle as po
@@ -124,6 +138,9 @@ def main():
     ap.add_argument("--nc", type=int, default=3)
     ap.add_argument("--ebn0", type=float, default=1.0)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="codewords for the CPU baseline (0 = skip)")
+    ap.add_argument("--data", default="harness", choices=["harness", "randn"],
+                    help="harness: the reference-compatible link chain generates the codewords and channel LLRs (default); "
+                         "randn: all-zero codeword + torch.randn noise")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
     args = ap.parse_args()
@@ -152,7 +169,14 @@ def main():
     B = args.batch
     dec = nb.Decoder(code, nb.METHOD_EMS, args.iters, ems_nm=args.nm, ems_nc=args.nc, fixed_iters=1, max_batch=B, device=local_rank)
     dec.profiling(True)
-    L = synth_llr(torch, code.q, code.N, B, args.ebn0, 173 + rank, dev)
+    if args.data == "harness":
+        L_host, tx_code = harness_llr(nb, B, args.ebn0, 173 + 1000003 * rank, args.iters, args.nm, args.nc)
+        L = torch.from_numpy(L_host).to(dev)
+        tx_dev = torch.from_numpy(tx_code).to(dev)
+        del L_host
+    else:
+        L = synth_llr(torch, code.q, code.N, B, args.ebn0, 173 + rank, dev)
+        tx_dev = torch.zeros((B, code.N), dtype=torch.int32, device=dev)
     out = torch.zeros((B, code.N), dtype=torch.int32, device=dev)
     conv = torch.zeros(B, dtype=torch.uint8, device=dev)
     its = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -201,13 +225,15 @@ def main():
         "metric": "decoded codewords/sec @ 50 iters, GF(256) N=512 rate-1/2",
         "value": value, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic" if args.data == "randn" else "synthetic (harness link chain: LFSR message, CRC-8, encoder, BPSK, AWGN seed 173+lane)",
         "config": {"workload": f"{CODE} over BPSK/AWGN Eb/N0={args.ebn0} dB, EMS nm={args.nm} nc={args.nc}, "
                                f"{args.iters} fixed iterations, batch {B} codewords per GPU",
                    "batch_per_gpu": B, "iters": args.iters, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
         "algorithmic_GBps_whole_job": total_cw * bytes_cw / dt / 1e9,
         "hbm_roofline_frac_whole_job": total_cw * bytes_cw / dt / 1e9 / (HBM_PEAK_GBS * world),
         "converged_frac": float(conv.float().mean().item()),
+        # sanity on the decoded words themselves: frames whose output equals the transmitted codeword / converged frames
+        "frames_correct_frac": float((out == tx_dev).all(dim=1).float().mean().item()),
         "phase_ms_per_step": {"vn": ms_vn / args.steps, "syndrome": ms_syn / args.steps, "cn": ms_cn / args.steps},
         "roofline": {"kernel": "cn_ems_q256_dc4_kernel<32, fused>" if fused else "cn_ems_q256_dc4_kernel<32>", "bound": "hbm", "achieved": cn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": cn_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(fused, B), "bytes_per_launch": cn_bytes_launch, "ms_per_launch": cn_ms},

@@ -1,5 +1,7 @@
 // nbldpc_amd/host/capi.cpp -- small C entry points over the host layer for the Python tests (ctypes).
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include "link.h"
 
 extern "C" {
@@ -27,15 +29,29 @@ int nblh_frontend(const char *profile, double ebn0, int frames, double *L_ch, in
 		lanes.back()->SetEbN0(link.sim, i);
 	}
 	if (sigma_out) *sigma_out = lanes[0]->sigma_n;
-	for (int f = 0; f < frames; f++)
-		for (int i = 0; i < P; i++) {
+	// lanes are independent (own RNG, PN register, buffers): run them on host threads, frame after frame per lane
+	auto work = [&](int lo, int hi) {
+		for (int i = lo; i < hi; i++) {
 			CComm &c = *lanes[i];
-			c.FrontEnd();
-			const size_t b = (size_t)f * P + i;
-			memcpy(L_ch + b * N * w, c.RX_LLR_SYM.data(), sizeof(double) * N * w);
-			for (int n = 0; n < N; n++) tx_code[b * N + n] = c.TX_CODE_SYM[n];
-			for (int n = 0; n < K; n++) tx_msg[b * K + n] = c.TX_MSG_SYM[n];
+			for (int f = 0; f < frames; f++) {
+				c.FrontEnd();
+				const size_t b = (size_t)f * P + i;
+				memcpy(L_ch + b * N * w, c.RX_LLR_SYM.data(), sizeof(double) * N * w);
+				if (tx_code) for (int n = 0; n < N; n++) tx_code[b * N + n] = c.TX_CODE_SYM[n];
+				if (tx_msg) for (int n = 0; n < K; n++) tx_msg[b * K + n] = c.TX_MSG_SYM[n];
+			}
 		}
+	};
+	int T = (int)std::thread::hardware_concurrency();
+	if (const char *e = getenv("NBL_HOST_THREADS")) T = atoi(e);
+	if (T > 16) T = 16;
+	if (T > P) T = P;
+	if (T <= 1) work(0, P);
+	else {
+		std::vector<std::thread> th;
+		for (int t = 0; t < T; t++) th.emplace_back(work, (int)((long long)P * t / T), (int)((long long)P * (t + 1) / T));
+		for (auto &x : th) x.join();
+	}
 	return 0;
 }
 

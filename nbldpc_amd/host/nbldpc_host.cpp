@@ -58,7 +58,7 @@ bool CNBLDPC::Initial(CSimulation &sim, int device, int fixed_iters)
 	p.tems_nr = sim.tems_nr; p.tems_nc = sim.tems_nc; p.tems_factor = sim.tems_factor; p.tems_offset = sim.tems_offset;
 	p.fixed_iters = fixed_iters;
 	p.poll_every = fixed_iters ? 0 : 2;
-	p.max_batch = sim.parallel;
+	p.max_batch = 0; // the workspace is sized at the first DecodingBatch call
 	if (dec) { nbl_destroy(dec); dec = nullptr; }
 	nbl_status st = nbl_create(&code, mul.data(), inv.data(), &p, device, &dec);
 	if (st != NBL_OK) {
