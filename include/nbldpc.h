@@ -95,6 +95,23 @@ nbl_status nbl_decode_batch(nbl_decoder *dec, const double *L_ch, int32_t B, int
 nbl_status nbl_decode_batch_device(nbl_decoder *dec, const double *d_L_ch, int32_t B, int32_t *d_out_sym,
                                    uint8_t *d_converged, int32_t *d_iters, void *stream);
 
+/* ---- device-side soft demodulator: L_ch is built in HBM from the received samples ------------------
+ * Replaces CComm::Demodulate (Comm.cpp:340-407) for the two cases the reference implements: BPSK (modOrder == 2, :342-380)
+ * and one constellation point per code symbol (modOrder == GFq, :382-398), with the reference's expression order, so
+ * the LLRs are bit-identical to the host computation.  Host->device traffic drops from N(q-1) doubles to 2 L doubles per
+ * codeword (16x for BPSK GF(256), 128x for 256-QAM). */
+typedef struct nbl_demod_desc {
+	int32_t mod_order;           /* 2, or q                                                              */
+	int32_t n_mod_sym;           /* L = received samples per codeword (MOD_SYM_LEN)                      */
+	const double *constellation; /* [mod_order][2] (Real, Image) = CONSTELLATION[]; used when mod_order == q */
+	const int32_t *src;          /* mod_order == 2: [N*p] sample index carrying code bit b, -1 = punctured (LLR 0, :350-354)
+	                                mod_order == q: [N]   sample index of code symbol n,    -1 = punctured (:386-393)   */
+} nbl_demod_desc;
+nbl_status nbl_set_demodulator(nbl_decoder *dec, const nbl_demod_desc *demod);
+/* rx: HOST buffer [B][L][2] (Real, Image) = RX_MOD_SYM after the channel; sigma = sigma_n (Comm.cpp:176-177) */
+nbl_status nbl_decode_batch_samples(nbl_decoder *dec, const double *rx, double sigma, int32_t B, int32_t *out_sym,
+                                    uint8_t *converged, int32_t *iters);
+
 /* Message state of codeword b after the last decode call (host buffers, any may be NULL):
  * post [N][q-1], v2c [E][q-1], c2v [E][q-1], edges in variable-major order.  For parity tests. */
 nbl_status nbl_read_state(nbl_decoder *dec, int32_t b, double *post, double *v2c, double *c2v);

@@ -17,6 +17,7 @@ METHOD_BP, METHOD_EMS, METHOD_TEMS = 1, 2, 4
 
 # every symbol include/nbldpc.h declares
 EXPORTS = ("nbl_abi_version", "nbl_create", "nbl_destroy", "nbl_decode_batch", "nbl_decode_batch_device",
+           "nbl_set_demodulator", "nbl_decode_batch_samples",
            "nbl_read_state", "nbl_set_record_state", "nbl_set_profiling", "nbl_last_timing", "nbl_last_error",
            "nbl_workspace_bytes")
 
@@ -145,6 +146,33 @@ class Decoder:
     def decode_device(self, d_L_ch, B, d_out, d_conv=None, d_iters=None, stream=None):
         """Raw device pointers (ints); asynchronous on `stream` (a hipStream_t as int, None = decoder stream)."""
         self._chk(self.lib.nbl_decode_batch_device(self.h, d_L_ch, B, d_out, d_conv, d_iters, stream))
+
+    def set_demodulator(self, mod_order, n_mod_sym, src, constellation=None):
+        """src: int32 sample index per code bit (BPSK) / per code symbol (q-ary), -1 = punctured."""
+        class Demod(C.Structure):
+            _fields_ = [("mod_order", C.c_int32), ("n_mod_sym", C.c_int32), ("constellation", C.c_void_p), ("src", C.c_void_p)]
+        self._dm_src = np.ascontiguousarray(src, dtype=np.int32)
+        self._dm_cons = None if constellation is None else np.ascontiguousarray(constellation, dtype=np.float64)
+        d = Demod(mod_order, n_mod_sym, None if self._dm_cons is None else self._dm_cons.ctypes.data, self._dm_src.ctypes.data)
+        self.lib.nbl_set_demodulator.argtypes = [C.c_void_p, C.c_void_p]
+        self._chk(self.lib.nbl_set_demodulator(self.h, C.byref(d)))
+
+    def decode_samples(self, rx, sigma):
+        """rx: [B][L][2] received samples -> (out, converged, iters); L_ch is built on the device."""
+        rx = np.ascontiguousarray(rx, dtype=np.float64)
+        B = rx.shape[0]
+        out = np.zeros((B, self.code.N), dtype=np.int32)
+        conv = np.zeros(B, dtype=np.uint8)
+        iters = np.zeros(B, dtype=np.int32)
+        self.lib.nbl_decode_batch_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.nbl_decode_batch_samples(self.h, rx.ctypes.data, sigma, B, out.ctypes.data, conv.ctypes.data, iters.ctypes.data))
+        return out, conv, iters
+
+    def read_lch(self, b):
+        L = np.zeros((self.code.N, self.code.q - 1))
+        self.lib.nbl_debug_read_lch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        self._chk(self.lib.nbl_debug_read_lch(self.h, b, L.ctypes.data))
+        return L
 
     def record_state(self, on=True):
         self._chk(self.lib.nbl_set_record_state(self.h, int(on)))

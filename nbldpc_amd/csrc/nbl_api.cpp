@@ -31,6 +31,12 @@ struct nbl_decoder {
 	bool all_dv2 = false;       // every variable has degree 2
 	double *c2v_alt = nullptr;  // second c2v buffer of the fused EMS iteration (flooding schedule -> double buffer)
 	const double *last_c2v = nullptr;
+	// device-side demodulator (nbl_set_demodulator)
+	int dm_order = 0, dm_L = 0;
+	double *d_cons = nullptr;
+	int *d_src = nullptr;
+	double *d_rx = nullptr;
+	size_t d_rx_cap = 0;
 	int force_generic = 0;      // debug: 1 = always the generic kernels, 2 = specialised kernels but no VN/CN fusion
 	bool profiling = false;
 	hipEvent_t ev[2] = {nullptr, nullptr};
@@ -232,6 +238,9 @@ extern "C" void nbl_destroy(nbl_decoder *d)
 	if (d->stream) { (void)hipStreamSynchronize(d->stream); }
 	free_workspace(d);
 	for (void *p : d->graph_allocs) (void)hipFree(p);
+	if (d->d_src) (void)hipFree(d->d_src);
+	if (d->d_cons) (void)hipFree(d->d_cons);
+	if (d->d_rx) (void)hipFree(d->d_rx);
 	for (auto &e : d->ev)
 		if (e) (void)hipEventDestroy(e);
 	for (auto &e : d->pev) (void)hipEventDestroy(e);
@@ -417,6 +426,76 @@ extern "C" nbl_status nbl_decode_batch(nbl_decoder *d, const double *L_ch, int32
 	if (converged) HIP_TRY(d, hipMemcpyAsync(converged, d->w.done, (size_t)B, hipMemcpyDeviceToHost, d->stream));
 	if (iters) HIP_TRY(d, hipMemcpyAsync(iters, d->w.iters, (size_t)B * 4, hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(d, hipStreamSynchronize(d->stream));
+	return NBL_OK;
+}
+
+extern "C" nbl_status nbl_set_demodulator(nbl_decoder *d, const nbl_demod_desc *dm)
+{
+	if (!d || !dm || !dm->src) return NBL_ERR_ARG;
+	const int q = d->g.q, N = d->g.N, p = d->g.p;
+	if (dm->mod_order != 2 && dm->mod_order != q) {
+		d->err = "This module ( code order ~= modulation order ) haven't been developed!"; // Comm.cpp:400-404
+		return NBL_ERR_UNSUPPORTED;
+	}
+	if (dm->n_mod_sym <= 0 || (dm->mod_order == q && !dm->constellation)) return NBL_ERR_ARG;
+	HIP_TRY(d, hipSetDevice(d->device));
+	const size_t nsrc = dm->mod_order == 2 ? (size_t)N * p : (size_t)N;
+	for (size_t i = 0; i < nsrc; i++)
+		if (dm->src[i] >= dm->n_mod_sym) { d->err = "demodulator source index out of range"; return NBL_ERR_ARG; }
+	if (d->d_src) (void)hipFree(d->d_src);
+	if (d->d_cons) (void)hipFree(d->d_cons);
+	d->d_src = nullptr; d->d_cons = nullptr;
+	HIP_TRY(d, hipMalloc((void **)&d->d_src, nsrc * 4));
+	HIP_TRY(d, hipMemcpy(d->d_src, dm->src, nsrc * 4, hipMemcpyHostToDevice));
+	if (dm->mod_order == q) {
+		HIP_TRY(d, hipMalloc((void **)&d->d_cons, (size_t)q * 16));
+		HIP_TRY(d, hipMemcpy(d->d_cons, dm->constellation, (size_t)q * 16, hipMemcpyHostToDevice));
+	}
+	d->dm_order = dm->mod_order;
+	d->dm_L = dm->n_mod_sym;
+	return NBL_OK;
+}
+
+static nbl_status run_iterations(nbl_decoder *d, const double *d_Lin, int B, hipStream_t st);
+
+extern "C" nbl_status nbl_decode_batch_samples(nbl_decoder *d, const double *rx, double sigma, int32_t B, int32_t *out_sym,
+                                               uint8_t *converged, int32_t *iters)
+{
+	if (!d || !rx || !out_sym || B < 0 || !(sigma > 0)) return NBL_ERR_ARG;
+	if (!d->dm_order) { d->err = "nbl_set_demodulator has not been called"; return NBL_ERR_ARG; }
+	if (B == 0) return NBL_OK;
+	HIP_TRY(d, hipSetDevice(d->device));
+	nbl_status s = ensure_workspace(d, B);
+	if (s) return s;
+	const size_t bytes = (size_t)B * d->dm_L * 16;
+	if (bytes > d->d_rx_cap) {
+		if (d->d_rx) (void)hipFree(d->d_rx);
+		d->d_rx = nullptr;
+		HIP_TRY(d, hipMalloc((void **)&d->d_rx, bytes));
+		d->d_rx_cap = bytes;
+	}
+	HIP_TRY(d, hipMemcpyAsync(d->d_rx, rx, bytes, hipMemcpyHostToDevice, d->stream));
+	HIP_TRY(d, nbl_launch_demod(d->d_rx, d->dm_L, sigma, d->dm_order, d->d_cons, d->d_src, d->g, d->w, B, d->stream));
+	if ((s = run_iterations(d, nullptr, B, d->stream))) return s;
+	HIP_TRY(d, hipMemcpyAsync(out_sym, d->w.out, (size_t)B * d->g.N * 4, hipMemcpyDeviceToHost, d->stream));
+	if (converged) HIP_TRY(d, hipMemcpyAsync(converged, d->w.done, (size_t)B, hipMemcpyDeviceToHost, d->stream));
+	if (iters) HIP_TRY(d, hipMemcpyAsync(iters, d->w.iters, (size_t)B * 4, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(d, hipStreamSynchronize(d->stream));
+	return NBL_OK;
+}
+
+// Diagnostic only: channel LLRs of codeword b as the decoder holds them, [N][q-1]
+extern "C" nbl_status nbl_debug_read_lch(nbl_decoder *d, int32_t b, double *out)
+{
+	if (!d || !out || b < 0 || b >= d->last_B) return NBL_ERR_ARG;
+	HIP_TRY(d, hipSetDevice(d->device));
+	const int q = d->g.q, N = d->g.N;
+	double *tmp = nullptr;
+	HIP_TRY(d, hipMalloc((void **)&tmp, (size_t)N * (q - 1) * 8));
+	HIP_TRY(d, nbl_launch_unpad(d->w.Lch + (size_t)b * N * q, tmp, nullptr, N, q, d->stream));
+	HIP_TRY(d, hipMemcpyAsync(out, tmp, (size_t)N * (q - 1) * 8, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(d, hipStreamSynchronize(d->stream));
+	(void)hipFree(tmp);
 	return NBL_OK;
 }
 

@@ -4,6 +4,8 @@
 #include "nbl_common.h"
 
 hipError_t nbl_launch_init(const double *d_Lin, const NblGraphDev &g, const NblWork &w, int B, int write_v2c, hipStream_t st);
+hipError_t nbl_launch_demod(const double *d_rx, int L, double sigma, int mod_order, const double *d_cons, const int *d_src,
+                            const NblGraphDev &g, const NblWork &w, int B, hipStream_t st);
 hipError_t nbl_launch_vn(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool damp, hipStream_t st);
 hipError_t nbl_launch_syn(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);
 hipError_t nbl_launch_cn_ems(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);

@@ -21,7 +21,7 @@ __global__ void init_kernel(const double *__restrict__ Lin, NblGraphDev g, NblWo
 	for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
 		int a = (int)(i % q);
 		long long bn = i / q;
-		w.Lch[i] = a ? Lin[bn * (q - 1) + (a - 1)] : 0.0;
+		if (Lin) w.Lch[i] = a ? Lin[bn * (q - 1) + (a - 1)] : 0.0; // else: demod_kernel has already filled Lch
 	}
 	long long etotal = (long long)B * g.E * q;
 	for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < etotal; i += (long long)gridDim.x * blockDim.x)
@@ -35,7 +35,7 @@ __global__ void init_kernel(const double *__restrict__ Lin, NblGraphDev g, NblWo
 			// variable of edge e: binary search in voff
 			int lo = 0, hi = g.N;
 			while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (g.voff[mid] <= e) lo = mid; else hi = mid; }
-			w.v2c[i] = a ? Lin[(b * g.N + lo) * (q - 1) + (a - 1)] : 0.0;
+			w.v2c[i] = a ? (Lin ? Lin[(b * g.N + lo) * (q - 1) + (a - 1)] : w.Lch[(b * g.N + lo) * q + a]) : 0.0;
 		}
 	}
 	for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x) {
@@ -43,6 +43,45 @@ __global__ void init_kernel(const double *__restrict__ Lin, NblGraphDev g, NblWo
 		w.iters[i] = 0;
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0) *w.n_done = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// soft demodulator: received samples -> symbol LLRs, written straight into the padded Lch layout.
+// Expression order is CComm::Demodulate's (Comm.cpp:356, :364-378 for BPSK; :394-395 for q-ary constellations).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void demod_kernel(const double *__restrict__ rx, int L, double sigma_n, int mod_order, int p,
+                                                    const double *__restrict__ cons, const int *__restrict__ src, NblGraphDev g,
+                                                    NblWork w, int B)
+{
+	const int lane = lane_id();
+	const long long node = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (node >= (long long)B * g.N) return;
+	const int b = (int)(node / g.N), n = (int)(node % g.N), q = g.q;
+	double *dst = w.Lch + ((size_t)b * g.N + n) * q;
+	const double *r = rx + (size_t)b * L * 2;
+	if (mod_order == 2) {
+		double bl[8];
+		for (int k = 0; k < 8; k++) {
+			const int sidx = (k < p) ? src[n * p + k] : -1;
+			bl[k] = (sidx < 0) ? 0.0 : -2 * r[2 * sidx] / (sigma_n * sigma_n);
+		}
+		for (int a = lane; a < q; a += 64) {
+			double acc = 0;
+#pragma unroll
+			for (int k = 0; k < 8; k++)
+				if (k < p && (a & (1 << k)) != 0) acc += bl[k];
+			dst[a] = a ? acc : 0.0;
+		}
+	} else {
+		const int sidx = src[n];
+		const double c0r = cons[0], c0i = cons[1];
+		const double re = sidx < 0 ? 0.0 : r[2 * sidx], im = sidx < 0 ? 0.0 : r[2 * sidx + 1];
+		for (int a = lane; a < q; a += 64) {
+			const double cr = cons[2 * a], ci = cons[2 * a + 1];
+			const double num = (2 * re - c0r - cr) * (cr - c0r) + (2 * im - c0i - ci) * (ci - c0i);
+			dst[a] = (a == 0 || sidx < 0) ? 0.0 : num / (2 * sigma_n * sigma_n);
+		}
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -508,6 +547,15 @@ hipError_t nbl_launch_init(const double *d_Lin, const NblGraphDev &g, const NblW
 	int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
 	if (blocks < 1) blocks = 1;
 	hipLaunchKernelGGL(init_kernel, dim3(blocks), dim3(256), 0, st, d_Lin, g, w, B, write_v2c);
+	return hipGetLastError();
+}
+
+hipError_t nbl_launch_demod(const double *d_rx, int L, double sigma, int mod_order, const double *d_cons, const int *d_src,
+                            const NblGraphDev &g, const NblWork &w, int B, hipStream_t st)
+{
+	long long nodes = (long long)B * g.N;
+	dim3 grid((unsigned)((nodes + 3) / 4)), block(256);
+	demod_kernel<<<grid, block, 0, st>>>(d_rx, L, sigma, mod_order, g.p, d_cons, d_src, g, w, B);
 	return hipGetLastError();
 }
 

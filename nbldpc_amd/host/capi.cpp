@@ -59,7 +59,9 @@ int nblh_frontend(const char *profile, double ebn0, int frames, double *L_ch, in
 int nblh_simulate(const char *profile, int device, double *rows, int max_rows)
 {
 	CLink link;
-	if (!link.Initial(profile, device)) return -1;
+	// device = -2: rehearsal of the multi-GPU split on a one-GPU box (two decoders, both on device 0)
+	const std::vector<int> devs = device == -2 ? std::vector<int>{0, 0} : std::vector<int>{device};
+	if (!link.Initial(profile, devs)) return -1;
 	int n = 0;
 	while (link.sim.NextSNR()) {
 		link.BeginSNR();

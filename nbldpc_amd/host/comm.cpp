@@ -99,6 +99,33 @@ int CComm::FrontEnd()
 	return Demodulate();
 }
 
+int CComm::FrontEndToChannel()
+{
+	GenerateMessage();
+	Encode();
+	Puncture();
+	Modulate();
+	return Channel_AWGN();
+}
+
+// the index bookkeeping of Demodulate (Comm.cpp:348-357 / :384-396) as a table: -1 marks a punctured position
+void CComm::DemodSource(std::vector<int> &src) const
+{
+	src.clear();
+	int pi = 0;
+	if (modOrder == 2) {
+		for (int b = 0; b < CODE_BIT_LEN; b++) {
+			if (PUN_BIT_LEN != 0 && pi < PUN_BIT_LEN && PUN_BIT[pi] == b) { pi++; src.push_back(-1); }
+			else src.push_back(b - pi);
+		}
+	} else {
+		for (int s = 0; s < CODE_SYM_LEN; s++) {
+			if (PUN_SYM_LEN != 0 && pi < PUN_SYM_LEN && PUN_SYM[pi] == s) { pi++; src.push_back(-1); }
+			else src.push_back(s - pi);
+		}
+	}
+}
+
 // 11-stage shift register, output r10, feedback r10 ^ r3 after the shift (Comm.cpp:241-252)
 int CComm::GenPN()
 {

@@ -32,6 +32,8 @@ public:
 	bool Initial(CSimulation &sim, int parallel_order, CNBLDPC *shared);
 	double SetEbN0(CSimulation &sim, int parallel_order);
 	int FrontEnd();
+	int FrontEndToChannel(); // everything up to Channel_AWGN: the demodulator runs on the device
+	void DemodSource(std::vector<int> &src) const; // which received sample carries each code bit (BPSK) / code symbol (q-ary)
 	int GenerateMessage();
 	int GenPN();
 	void CRCEncode(int *seqOut, const int *seqIn, int seqInLen, int crcLen, int crc24Type);

@@ -8,14 +8,19 @@
 class CLink {
 public:
 	CSimulation sim;
-	CNBLDPC code;
+	CNBLDPC code;                      // code parameters + encoder + the decoder of devices[0]
+	std::vector<std::unique_ptr<CNBLDPC>> extra; // one more decoder per additional GPU (lanes sharded, no collective)
+	std::vector<int> devices;
 	std::vector<std::unique_ptr<CComm>> lanes;
 	std::vector<double> L_batch;       // [parallel][N][q-1]
+	bool device_demod = false;         // NBL_DEVICE_DEMOD=1: ship received samples, demodulate on the GPU
+	std::vector<double> rx_batch;      // [parallel][MOD_SYM_LEN][2]
 	std::vector<int> out_batch, iters;
 	std::vector<uint8_t> conv;
 	std::string error;
 
 	bool Initial(const std::string &profile, int device = 0);
+	bool Initial(const std::string &profile, const std::vector<int> &device_list);
 	void BeginSNR();                   // ClearSimuCount + SetEbN0 on every lane
 	bool Cycle();                      // front-ends, one batched decode, Err per lane in lane order
 	void RunAll(bool verbose);

@@ -130,6 +130,23 @@ int CNBLDPC::DecodingBatch(const double *L_ch, int B, int *out, uint8_t *converg
 	return 0;
 }
 
+int CNBLDPC::SetDemodulator(int mod_order, int n_mod_sym, const double *constellation, const int *src)
+{
+	if (!dec) { error = "decoder not initialised"; return -1; }
+	nbl_demod_desc dm = {mod_order, n_mod_sym, constellation, src};
+	nbl_status st = nbl_set_demodulator(dec, &dm);
+	if (st != NBL_OK) { error = nbl_last_error(dec); std::cerr << error << std::endl; return (int)st; }
+	return 0;
+}
+
+int CNBLDPC::DecodingBatchSamples(const double *rx, double sigma, int B, int *out, uint8_t *converged, int *iters)
+{
+	if (!dec) { error = "decoder not initialised"; return -1; }
+	nbl_status st = nbl_decode_batch_samples(dec, rx, sigma, B, out, converged, iters);
+	if (st != NBL_OK) { error = nbl_last_error(dec); std::cerr << error << std::endl; return (int)st; }
+	return 0;
+}
+
 int CNBLDPC::Decoding(double **L_ch, int *DecodeOutput, int *, int *) // NBLDPC.cpp:607
 {
 	std::vector<double> flat((size_t)CodeLen * (GFq - 1));

@@ -36,6 +36,9 @@ public:
 	int Decoding(double **L_ch, int *DecodeOutput, int *RelySeri_symbol, int *RelySeri_bit);
 	// L_ch [B][CodeLen][GFq-1]; out [B][CodeLen]; converged [B] (may be null); iters [B] (may be null). 0 on success.
 	int DecodingBatch(const double *L_ch, int B, int *out, uint8_t *converged, int *iters);
+	// device-side demodulation (replaces CComm::Demodulate, Comm.cpp:340-407): rx [B][L][2] received samples
+	int SetDemodulator(int mod_order, int n_mod_sym, const double *constellation, const int *src);
+	int DecodingBatchSamples(const double *rx, double sigma, int B, int *out, uint8_t *converged, int *iters);
 	const std::string &LastError() const { return error; }
 	nbl_decoder *Handle() const { return dec; }
 
