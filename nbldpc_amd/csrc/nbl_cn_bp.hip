@@ -12,42 +12,92 @@
 //
 // Numerics: the reference accumulates the log-sum-exp sequentially, pairwise, in 80-bit long double under g++
 // (64-bit under its original MSVC).  A GPU has neither 80-bit registers nor glibc's expl/logl, so bit parity of the LLRs
-// is impossible by construction (SURVEY 8c hazard 3); here each LSE is evaluated max-first, m + log(sum exp(t - m)), in
-// FP64.  Parity for this method is defined on hard decisions, convergence flags and FER, with LLRs within 1e-9
+// is impossible by construction (SURVEY 8c hazard 3); here each LSE is evaluated in FP64 as described at lse_conv below.  Parity for this method is defined on hard decisions, convergence flags and FER, with LLRs within 1e-9
 // of the oracle's FP64 restatement (tests/test_gpu_parity.py).
 #include <hip/hip_runtime.h>
 #include "nbl_device.h"
 #include "nbl_kernels.h"
 
-// out[b] = LSE_x(L1[x] + L2[b^x]) - LSE_x(L1[x] + L2[x]) for the lane's symbols b; L1, L2, out: Q doubles in LDS, [0] = 0
+// out[b] = LSE_x(L1[x] + L2[b^x]) - LSE_x(L1[x] + L2[x]) for the lane's symbols b; L1, L2, out: Q doubles in LDS, [0] = 0.
+//
+// Evaluation: each input is exponentiated ONCE (2Q exponentials per convolution instead of Q^2), the XOR convolution itself is
+// a sum of products (all terms positive: no cancellation), one logarithm per output.
+//   * narrow inputs (range(L1) + range(L2) < 600): plain doubles, e^(L-max), one FMA per term;
+//   * wide inputs (LLRs thousands apart, e.g. high-order QAM at high SNR): every probability is kept as mantissa x 2^E with a
+//     separate 32-bit exponent, the running sum carries its own exponent (v_ldexp_f64 rescales exactly), so no term is ever
+//     lost to underflow -- the reference's log-domain formulation has unlimited range and so has this one.
+struct __attribute__((aligned(16))) XP { double m; int e; int pad; }; // value = m * 2^e, m in [1,2)
+
 template <int Q>
-__device__ __forceinline__ void lse_conv(const double *L1, const double *L2, double *out, int lane)
+__device__ __forceinline__ void lse_conv(const double *L1, const double *L2, double *out, XP *PA, XP *PB, int lane)
 {
 	constexpr int NS = Fld<Q>::NS;
-	double mx[NS], acc[NS];
-#pragma unroll
-	for (int i = 0; i < NS; i++) mx[i] = NBL_NEG_INF;
-	for (int x = 0; x < Q; x++) {
-		const double a = L1[x];
-#pragma unroll
-		for (int i = 0; i < NS; i++) {
-			int bsym = lane + 64 * i;
-			if (bsym < Q) mx[i] = dmax(mx[i], a + L2[bsym ^ x]);
-		}
+	double m1 = NBL_NEG_INF, m2 = NBL_NEG_INF, n1 = __builtin_huge_val(), n2 = __builtin_huge_val();
+	for (int s = lane; s < Q; s += 64) {
+		m1 = dmax(m1, L1[s]); m2 = dmax(m2, L2[s]);
+		n1 = dmin(n1, L1[s]); n2 = dmin(n2, L2[s]);
 	}
 #pragma unroll
-	for (int i = 0; i < NS; i++) acc[i] = 0.0;
-	for (int x = 0; x < Q; x++) {
-		const double a = L1[x];
-#pragma unroll
-		for (int i = 0; i < NS; i++) {
-			int bsym = lane + 64 * i;
-			if (bsym < Q) acc[i] += exp((a + L2[bsym ^ x]) - mx[i]);
-		}
+	for (int off = 32; off >= 1; off >>= 1) {
+		m1 = dmax(m1, __shfl_xor(m1, off, 64)); m2 = dmax(m2, __shfl_xor(m2, off, 64));
+		n1 = dmin(n1, __shfl_xor(n1, off, 64)); n2 = dmin(n2, __shfl_xor(n2, off, 64));
 	}
+	const bool narrow = (m1 - n1) + (m2 - n2) < 600.0; // wave-uniform
 	double lse[NS];
+	if (narrow) {
+		double *A = (double *)PA, *B = (double *)PB;
+		for (int s = lane; s < Q; s += 64) { A[s] = exp(L1[s] - m1); B[s] = exp(L2[s] - m2); }
+		__syncthreads();
+		double acc[NS];
 #pragma unroll
-	for (int i = 0; i < NS; i++) lse[i] = mx[i] + log(acc[i]);
+		for (int i = 0; i < NS; i++) acc[i] = 0.0;
+#pragma unroll 4
+		for (int x = 0; x < Q; x++) {
+			const double a = A[x];
+#pragma unroll
+			for (int i = 0; i < NS; i++) {
+				int bsym = lane + 64 * i;
+				if (bsym < Q) acc[i] = __fma_rn(a, B[bsym ^ x], acc[i]);
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < NS; i++) lse[i] = (log(acc[i]) + m1) + m2;
+	} else {
+		const double LOG2E = 1.4426950408889634, LN2 = 0.6931471805599453;
+		for (int s = lane; s < Q; s += 64) {
+			const double y1 = (L1[s] - m1) * LOG2E, y2 = (L2[s] - m2) * LOG2E;
+			const double f1 = floor(y1), f2 = floor(y2);
+			XP a, b;
+			a.m = exp2(y1 - f1); a.e = (int)dmax(f1, -1.0e9); a.pad = 0;
+			b.m = exp2(y2 - f2); b.e = (int)dmax(f2, -1.0e9); b.pad = 0;
+			PA[s] = a;
+			PB[s] = b;
+		}
+		__syncthreads();
+		double acc[NS];
+		int ex[NS];
+#pragma unroll
+		for (int i = 0; i < NS; i++) { acc[i] = 0.0; ex[i] = -2000000000; }
+#pragma unroll 2
+		for (int x = 0; x < Q; x++) {
+			const XP a = PA[x];
+#pragma unroll
+			for (int i = 0; i < NS; i++) {
+				int bsym = lane + 64 * i;
+				if (bsym < Q) {
+					const XP b = PB[bsym ^ x];
+					const int e = a.e + b.e;
+					const int top = e > ex[i] ? e : ex[i];
+					// both rescalings are exact (power of two); differences beyond the double range give 0
+					const int d0 = ex[i] - top, d1 = e - top;
+					acc[i] = ldexp(acc[i], d0 < -2000 ? -2000 : d0) + ldexp(a.m * b.m, d1 < -2000 ? -2000 : d1);
+					ex[i] = top;
+				}
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < NS; i++) lse[i] = ((log(acc[i]) + (double)ex[i] * LN2) + m1) + m2;
+	}
 	const double norm = read_lane_f64(lse[0], 0); // b = 0
 	__syncthreads();
 #pragma unroll
@@ -72,6 +122,8 @@ __global__ __launch_bounds__(64) void cn_bp_kernel(NblGraphDev g, NblWork w, Nbl
 	double *F = Pp + mdc * Q;      // [mdc][Q] F[k] = edges 0..k-1   (k = 1..dc-1)
 	double *R = F + mdc * Q;       // [mdc][Q] R[k] = edges dc-1..k+1 (k = dc-2..0)
 	double *T = R + mdc * Q;       // [Q] scratch
+	XP *PA = (XP *)(T + Q);        // [Q] e^(L1 - max), plain double or mantissa/exponent
+	XP *PB = PA + Q;               // [Q] e^(L2 - max)
 
 	const double *V = w.v2c + (size_t)b * g.E * Q;
 	double *C = w.c2v + ((size_t)b * g.E + c0) * Q;
@@ -90,15 +142,15 @@ __global__ __launch_bounds__(64) void cn_bp_kernel(NblGraphDev g, NblWork w, Nbl
 	// forward partials: F[1] = p_0, F[k+1] = conv(F[k], p_k)
 	for (int s = lane; s < Q; s += 64) { F[1 * Q + s] = Pp[s]; R[(dc - 2) * Q + s] = Pp[(dc - 1) * Q + s]; }
 	__syncthreads();
-	for (int k = 1; k + 1 <= dc - 1; k++) lse_conv<Q>(F + k * Q, Pp + k * Q, F + (k + 1) * Q, lane);
+	for (int k = 1; k + 1 <= dc - 1; k++) lse_conv<Q>(F + k * Q, Pp + k * Q, F + (k + 1) * Q, PA, PB, lane);
 	// backward partials: R[dc-2] = p_dc-1, R[k-1] = conv(R[k], p_k)
-	for (int k = dc - 2; k >= 1; k--) lse_conv<Q>(R + k * Q, Pp + k * Q, R + (k - 1) * Q, lane);
+	for (int k = dc - 2; k >= 1; k--) lse_conv<Q>(R + k * Q, Pp + k * Q, R + (k - 1) * Q, PA, PB, lane);
 	// outputs
 	for (int d = 0; d < dc; d++) {
 		const double *src;
 		if (d == 0) src = R;                            // A1 = 0 (:757-760)
 		else if (d == dc - 1) src = F + (dc - 1) * Q;   // A2 = 0 (:761-764)
-		else { lse_conv<Q>(F + d * Q, R + d * Q, T, lane); src = T; }
+		else { lse_conv<Q>(F + d * Q, R + d * Q, T, PA, PB, lane); src = T; }
 		GfMul<Q> mh;
 		mh.init(g.c_h[c0 + d], g.poly, lane);
 		double *Cd = C + (size_t)d * Q;
@@ -125,7 +177,7 @@ __global__ __launch_bounds__(64) void cn_bp_kernel(NblGraphDev g, NblWork w, Nbl
 
 hipError_t nbl_launch_cn_bp(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
 {
-	const size_t lds = ((size_t)3 * g.maxdc + 1) * g.q * 8;
+	const size_t lds = ((size_t)3 * g.maxdc + 5) * g.q * 8;
 	dim3 grid((unsigned)((long long)r.B * g.M)), block(64);
 	NBL_DISPATCH_Q(g.q, {
 		if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)cn_bp_kernel<QQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
