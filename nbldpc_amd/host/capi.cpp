@@ -17,10 +17,8 @@ int nblh_frontend(const char *profile, double ebn0, int frames, double *L_ch, in
 	CLink link;
 	link.sim = sim;
 	CNBLDPC &code = link.code;
-	// Initial() creates the device decoder; for the front-end we only need the graph and the encoder, so a failure to
-	// create the device handle is tolerated here (and only here).
-	bool ok = code.Initial(link.sim, 0);
-	if (!ok && code.CodeLen == 0) return -2;
+	// the front-end needs the graph and the encoder only: no device decoder is created (device = -1)
+	if (!code.Initial(link.sim, -1)) return -2;
 	const int P = sim.parallel, N = code.CodeLen, K = code.CodeLen - code.ChkLen, w = code.GFq - 1;
 	std::vector<std::unique_ptr<CComm>> lanes;
 	for (int i = 0; i < P; i++) {
@@ -83,8 +81,7 @@ int nblh_encode(const char *profile, const int *msg, int count, int *code_out)
 	CSimulation sim;
 	if (sim.Initial(profile) != 0) return -1;
 	CNBLDPC code;
-	code.Initial(sim, 0);
-	if (code.CodeLen == 0) return -2;
+	if (!code.Initial(sim, -1)) return -2;
 	const int N = code.CodeLen, K = N - code.ChkLen;
 	std::vector<int> m(K);
 	for (int c = 0; c < count; c++) {

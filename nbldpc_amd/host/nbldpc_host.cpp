@@ -42,6 +42,8 @@ bool CNBLDPC::Initial(CSimulation &sim, int device, int fixed_iters)
 	if (sim.OSD_order >= 0) { error = "OSD post-processing is outside this decode path: set OSD_order to -1"; std::cerr << error << std::endl; return false; }
 	if (sim.randomMsg && !InitialEncode()) return false;
 
+	if (device < 0) return true; // host-only use (link-chain front-end, encoder): no decoder handle is created
+
 	// hand the graph and the parameters to the device library
 	std::vector<int32_t> vchk, vh, cvar, ch;
 	for (int n = 0; n < CodeLen; n++) for (int d = 0; d < VarDegree[n]; d++) { vchk.push_back(VarLink[n][d]); vh.push_back(VarLinkGFe[n][d]); }

@@ -31,7 +31,7 @@ public:
 	std::vector<std::vector<int>> VarLink, ChkLink, VarLinkGFe, ChkLinkGFe;
 	int DecodeMethod = 0;
 
-	bool Initial(CSimulation &sim, int device = 0, int fixed_iters = 0);
+	bool Initial(CSimulation &sim, int device = 0, int fixed_iters = 0); // device < 0: graph + encoder only, no GPU touched
 	int Encode(int *msg_sym, int *code_sym);
 	int Decoding(double **L_ch, int *DecodeOutput, int *RelySeri_symbol, int *RelySeri_bit);
 	// L_ch [B][CodeLen][GFq-1]; out [B][CodeLen]; converged [B] (may be null); iters [B] (may be null). 0 on success.

@@ -75,6 +75,9 @@ FER_SETS = {
                                  snr_begin=2.0, snr_stop=2.0, constellation="BPSK", min_sim_cycle=200)),
     "cfg2_ems_u128_p8": ("O2", dict(gfq=256, code=U128_256, method=2, max_iter=50, parallel=8, ems_nm=16, ems_nc=3,
                                     snr_begin=1.5, snr_step=0.5, snr_stop=2.5, constellation="BPSK", min_sim_cycle=250)),
+    # north-star code: 64 frames per point through the waterfall (1.0 / 1.5 / 2.0 dB), 16 lanes
+    "cfg3_ems_u512_p16": ("O2", dict(gfq=256, code=U512_256, method=2, max_iter=50, parallel=16, ems_nm=32, ems_nc=3,
+                                     snr_begin=1.0, snr_step=0.5, snr_stop=2.0, constellation="BPSK", min_sim_cycle=48)),
     "cfg4_tems_bds": ("O2", dict(gfq=64, code=BDS, method=4, max_iter=50, parallel=4, tems_nr=2, tems_nc=3, nqam=64,
                                  constellation="GRAY_64QAM", random_msg=0, snr_begin=3.0, snr_stop=4.0, min_sim_cycle=28)),
 }
