@@ -357,13 +357,16 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 				// every lane works out which of its four buckets would be the cut; the cut lane's answer is read back
 				const int pre = cum - tot, s0 = pre + hc[0][j], s1 = s0 + hc[1][j], s2 = s1 + hc[2][j];
 				const int bsel = (s0 >= NM) ? 0 : (s1 >= NM) ? 1 : (s2 >= NM) ? 2 : 3;
+				const int upto = (s0 >= NM) ? s0 : (s1 >= NM) ? s1 : (s2 >= NM) ? s2 : cum; // entries up to and including the cut bucket
 				const int bstar = 4 * lstar + __builtin_amdgcn_readlane(bsel, lstar);
+				const bool exact = __builtin_amdgcn_readlane(upto, lstar) == NM; // the cut bucket ends exactly at the nm-th entry
 #pragma unroll
 				for (int i = 0; i < 4; i++) {
 					ss[u].cand[i] = __ballot(bk[j][i] == bstar);
-					ss[u].gt[i] = ss[u].eq[i] = 0;
+					ss[u].gt[i] = exact ? __ballot(bk[j][i] <= bstar) : 0;
+					ss[u].eq[i] = 0;
 				}
-				ss[u].done = 0;
+				ss[u].done = exact ? 1 : 0;
 			}
 			for (int guard = 0; guard < 300 && !(ss[0].done && ss[1].done); guard++) {
 				select_step(v[jp], NM, ss[0]);
