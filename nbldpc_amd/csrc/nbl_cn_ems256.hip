@@ -244,6 +244,10 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		}
 	} else {
 		const double *Cp = w.c2v_prev + (size_t)b * g.E * Q;
+		// issue every load of the four edges before anything consumes one (24 x 16 B per lane in flight)
+		double2 l0[4], l1[4], a0[4], a1[4], b0[4], b1[4];
+		int nvar[4], eidx[4];
+		bool ownA[4];
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const int n = g.c_var[c0 + j], e = g.c_epos[c0 + j], e0 = g.voff[n];
@@ -251,16 +255,24 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			const double2 *pl = (const double2 *)(w.Lch + ((size_t)b * g.N + n) * Q);
 			const double2 *pa = (const double2 *)(Cp + (size_t)cpA * Q);
 			const double2 *pb = (const double2 *)(Cp + (size_t)cpB * Q);
-			const double2 l0 = pl[lane], l1 = pl[64 + lane], a0 = pa[lane], a1 = pa[64 + lane], b0 = pb[lane], b1 = pb[64 + lane];
-			double post[4] = {(l0.x + a0.x) + b0.x, (l0.y + a0.y) + b0.y, (l1.x + a1.x) + b1.x, (l1.y + a1.y) + b1.y};
-			const bool ownA = (e == e0); // this check is the variable's first edge
-			v[j][0] = post[0] - (ownA ? a0.x : b0.x);
-			v[j][1] = post[1] - (ownA ? a0.y : b0.y);
-			v[j][2] = post[2] - (ownA ? a1.x : b1.x);
-			v[j][3] = post[3] - (ownA ? a1.y : b1.y);
-			if (lane == 0) v[j][0] = 0.0;
+			l0[j] = pl[lane]; l1[j] = pl[64 + lane];
+			a0[j] = pa[lane]; a1[j] = pa[64 + lane];
+			b0[j] = pb[lane]; b1[j] = pb[64 + lane];
+			nvar[j] = n; eidx[j] = e;
+			ownA[j] = (e == e0); // this check is the variable's first edge
 			hcoef[j] = g.c_h[c0 + j];
-			if (ownA) {
+		}
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const int n = nvar[j], e = eidx[j];
+			double post[4] = {(l0[j].x + a0[j].x) + b0[j].x, (l0[j].y + a0[j].y) + b0[j].y, (l1[j].x + a1[j].x) + b1[j].x,
+			                  (l1[j].y + a1[j].y) + b1[j].y};
+			v[j][0] = post[0] - (ownA[j] ? a0[j].x : b0[j].x);
+			v[j][1] = post[1] - (ownA[j] ? a0[j].y : b0[j].y);
+			v[j][2] = post[2] - (ownA[j] ? a1[j].x : b1[j].x);
+			v[j][3] = post[3] - (ownA[j] ? a1[j].y : b1[j].y);
+			if (lane == 0) v[j][0] = 0.0;
+			if (ownA[j]) {
 				// hard decision (DecideLLRVector :1542-1562): lowest symbol among the maxima, 0 unless the maximum is positive
 				if (lane == 0) post[0] = 0.0;
 				const double pm = wave_max_f64(dmax(dmax(post[0], post[1]), dmax(post[2], post[3])));
