@@ -96,14 +96,16 @@ static bool fused_shape(const nbl_decoder *d)
 
 static nbl_status ensure_workspace(nbl_decoder *d, int B)
 {
-	if (B <= d->cap && (!d->record_state || d->w.post)) return NBL_OK;
+	// v2c only exists in HBM when something reads it: the unfused path, or state read-back
+	const bool want_v2c = !fused_shape(d) || d->record_state || d->force_generic != 0;
+	if (B <= d->cap && (!d->record_state || d->w.post) && (!want_v2c || d->w.v2c)) return NBL_OK;
 	int cap = B > d->cap ? B : d->cap;
 	free_workspace(d);
 	const size_t q = d->g.q, N = d->g.N, E = d->g.E;
 	size_t bytes = 0;
 	auto alloc = [&](void **p, size_t n) -> hipError_t { bytes += n; return hipMalloc(p, n); };
 	HIP_TRY(d, alloc((void **)&d->w.Lch, (size_t)cap * N * q * 8));
-	HIP_TRY(d, alloc((void **)&d->w.v2c, (size_t)cap * E * q * 8));
+	if (want_v2c) HIP_TRY(d, alloc((void **)&d->w.v2c, (size_t)cap * E * q * 8));
 	HIP_TRY(d, alloc((void **)&d->w.c2v, (size_t)cap * E * q * 8));
 	if (fused_shape(d)) HIP_TRY(d, alloc((void **)&d->c2v_alt, (size_t)cap * E * q * 8));
 	if (d->record_state) HIP_TRY(d, alloc((void **)&d->w.post, (size_t)cap * N * q * 8));
@@ -517,7 +519,10 @@ extern "C" nbl_status nbl_read_state(nbl_decoder *d, int32_t b, double *post, do
 		if (!d->w.post) { d->err = "state recording was off during the last decode (nbl_set_record_state)"; rc = NBL_ERR_ARG; }
 		else rc = grab(d->w.post + (size_t)b * N * q, nullptr, N, post);
 	}
-	if (!rc && v2c) rc = grab(d->w.v2c + (size_t)b * E * q, nullptr, E, v2c);
+	if (!rc && v2c) {
+		if (!d->w.v2c) { d->err = "v2c is not kept in HBM on the fused path unless state recording is on (nbl_set_record_state)"; rc = NBL_ERR_ARG; }
+		else rc = grab(d->w.v2c + (size_t)b * E * q, nullptr, E, v2c);
+	}
 	if (!rc && c2v) rc = grab((d->last_c2v ? d->last_c2v : d->w.c2v) + (size_t)b * E * q, d->d_e2c_map, E, c2v);
 	(void)hipFree(tmp);
 	return rc;
