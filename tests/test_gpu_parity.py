@@ -208,6 +208,35 @@ def test_random_ties_all_kernel_variants(oracle, nm, seed):
         dec.close()
 
 
+@pytest.mark.parametrize("method,codename,kw", [
+    (2, "divsalar.UNBLDPC.128.64.GF.256", dict(ems_nm=16, ems_nc=3)),
+    (2, "divsalar.UNBLDPC.128.64.GF.16", dict(ems_nm=8, ems_nc=2)),
+    (4, "BDS.576.288.GF.64", dict(tems_nr=2, tems_nc=3)),
+    (1, "divsalar.UNBLDPC.128.64.GF.16", dict()),
+])
+def test_non_finite_inputs_terminate(method, codename, kw):
+    """Garbage in (NaN, +-inf, 1e300) must not hang or fault any kernel: every data-dependent loop is bounded.  Outputs are
+    unspecified for such frames, but finite frames in the same batch must be unaffected (codewords never interact)."""
+    code = nb.Code(codename)
+    rng = np.random.default_rng(9)
+    B = 8
+    L = rng.normal(-3, 4, (B, code.N, code.q - 1))
+    clean = nb.Decoder(code, method, 5, **kw)
+    ref = clean.decode(L)
+    clean.close()
+    bad = L.copy()
+    bad[1, :, ::3] = np.nan
+    bad[3, ::2, :] = np.inf
+    bad[5, :, 1::2] = -np.inf
+    bad[6] *= 1e300
+    dec = nb.Decoder(code, method, 5, **kw)
+    out, conv, iters = dec.decode(bad)
+    dec.close()
+    for b in (0, 2, 4, 7):
+        assert np.array_equal(out[b], ref[0][b]) and conv[b] == ref[1][b] and iters[b] == ref[2][b]
+    assert out.min() >= 0 and out.max() < code.q
+
+
 def _bpsk_llr(code_sym, q, sigma, rng):
     """Symbol LLRs of codeword symbols sent over BPSK/AWGN in the reference's convention (Comm.cpp:276, :319, :340-380)."""
     p = q.bit_length() - 1
