@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	// (a) a 64-bucket histogram of [lmin, mtop] (LDS atomics + DPP prefix sum) finds the bucket that holds the nm-th best
 	// value -- bucketing only has to be monotone, so its arithmetic needs no care; (b) a ballot quickselect, restricted to
 	// that bucket, finds the cut exactly; ties at the cut are resolved by symbol, higher first (:1731).
-	bool mem[4][4];
+	int n0[4], n0p[4], n1p[4];
 	{
 		int bk[4][4];
 		int *H = (int *)U; // [256 buckets][4 edges] (spans U and P); lane l reads buckets 4l .. 4l+3
@@ -356,89 +356,75 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			hc[i][0] = h4.x; hc[i][1] = h4.y; hc[i][2] = h4.z; hc[i][3] = h4.w;
 		}
 		STAMP(2);
+		// per edge: locate the cut bucket, settle the members, compact them into the padded list image
+		// [even-symbol group | pad to 4 | odd-symbol group | pad to 4] (pads carry -inf and never win a max)
 #pragma unroll
-		for (int jp = 0; jp < 4; jp += 2) {
-			SelState ss[2];
+		for (int j = 0; j < 4; j++) {
+			const int tot = hc[0][j] + hc[1][j] + hc[2][j] + hc[3][j];
+			const int cum = wave_scan_add(tot);
+			const uint64_t reach = __ballot(cum >= NM);
+			const int lstar = reach ? __builtin_ctzll(reach) : 63;
+			// every lane works out which of its four buckets would be the cut; the cut lane's answer is read back
+			const int pre = cum - tot, s0 = pre + hc[0][j], s1 = s0 + hc[1][j], s2 = s1 + hc[2][j];
+			const int bsel = (s0 >= NM) ? 0 : (s1 >= NM) ? 1 : (s2 >= NM) ? 2 : 3;
+			const int upto = (s0 >= NM) ? s0 : (s1 >= NM) ? s1 : (s2 >= NM) ? s2 : cum; // entries up to and including the cut bucket
+			const int bstar = 4 * lstar + __builtin_amdgcn_readlane(bsel, lstar);
+			const bool exact = __builtin_amdgcn_readlane(upto, lstar) == NM; // the cut bucket ends exactly at the nm-th entry
+			uint64_t member[4];
+			if (exact) {
 #pragma unroll
-			for (int u = 0; u < 2; u++) {
-				const int j = jp + u;
-				const int tot = hc[0][j] + hc[1][j] + hc[2][j] + hc[3][j];
-				const int cum = wave_scan_add(tot);
-				const uint64_t reach = __ballot(cum >= NM);
-				const int lstar = reach ? __builtin_ctzll(reach) : 63;
-				// every lane works out which of its four buckets would be the cut; the cut lane's answer is read back
-				const int pre = cum - tot, s0 = pre + hc[0][j], s1 = s0 + hc[1][j], s2 = s1 + hc[2][j];
-				const int bsel = (s0 >= NM) ? 0 : (s1 >= NM) ? 1 : (s2 >= NM) ? 2 : 3;
-				const int upto = (s0 >= NM) ? s0 : (s1 >= NM) ? s1 : (s2 >= NM) ? s2 : cum; // entries up to and including the cut bucket
-				const int bstar = 4 * lstar + __builtin_amdgcn_readlane(bsel, lstar);
-				const bool exact = __builtin_amdgcn_readlane(upto, lstar) == NM; // the cut bucket ends exactly at the nm-th entry
+				for (int i = 0; i < 4; i++) member[i] = __ballot(bk[j][i] <= bstar);
+			} else {
+				SelState ss;
 #pragma unroll
-				for (int i = 0; i < 4; i++) {
-					ss[u].cand[i] = __ballot(bk[j][i] == bstar);
-					ss[u].gt[i] = exact ? __ballot(bk[j][i] <= bstar) : 0;
-					ss[u].eq[i] = 0;
+				for (int i = 0; i < 4; i++) { ss.cand[i] = __ballot(bk[j][i] == bstar); ss.gt[i] = ss.eq[i] = 0; }
+				ss.done = 0;
+				for (int guard = 0; guard < 300 && !ss.done; guard++) {
+					select_step(v[j], NM, ss);
+					if (st_on) st_acc[9]++;
 				}
-				ss[u].done = exact ? 1 : 0;
+				finish_members(ss, NM, member);
 			}
-			for (int guard = 0; guard < 300 && !(ss[0].done && ss[1].done); guard++) {
-				select_step(v[jp], NM, ss[0]);
-				select_step(v[jp + 1], NM, ss[1]);
-				if (st_on) st_acc[9]++;
+			// compaction straight from the (wave-uniform) member masks
+			uint64_t g0[4], g1[4];
+			int c0n = 0;
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const uint64_t even = __ballot(((tp[j] >> (8 * i)) & 1u) == 0u);
+				g0[i] = member[i] & even;
+				g1[i] = member[i] & ~even;
+				c0n += __popcll(g0[i]);
 			}
-#pragma unroll
-			for (int u = 0; u < 2; u++) {
-				uint64_t member[4];
-				finish_members(ss[u], NM, member);
-#pragma unroll
-				for (int i = 0; i < 4; i++) mem[jp + u][i] = __builtin_amdgcn_inverse_ballot_w64(member[i]);
+			n0[j] = c0n;
+			n0p[j] = (c0n + 3) & ~3;
+			n1p[j] = (NM - c0n + 3) & ~3;
+			ListEnt *Lj = lstp + j * NMP;
+			if (lane < 8) {
+				ListEnt pe;
+				pe.v = NBL_NEG_INF;
+				pe.t = 0;
+				pe.tt = 0;
+				const int n1 = NM - c0n;
+				const int pos = (lane < 4) ? c0n + lane : n0p[j] + n1 + (lane - 4);
+				const bool need = (lane < 4) ? (c0n + lane < n0p[j]) : (n1 + lane - 4 < n1p[j]);
+				if (need) Lj[pos] = pe;
 			}
-		}
-	}
-	STAMP(3);
-
-	// ---- compact the members into the padded list image: [even-symbol group | pad to 4 | odd-symbol group | pad to 4] ----
-	int n0[4], n0p[4], n1p[4];
-	__syncthreads();
+			int base0 = 0, base1 = n0p[j];
 #pragma unroll
-	for (int j = 0; j < 4; j++) {
-		uint64_t g0[4], g1[4];
-		int c0n = 0;
-#pragma unroll
-		for (int i = 0; i < 4; i++) {
-			const bool odd = (tp[j] >> (8 * i)) & 1u;
-			g0[i] = __ballot(mem[j][i] && !odd);
-			g1[i] = __ballot(mem[j][i] && odd);
-			c0n += __popcll(g0[i]);
-		}
-		n0[j] = c0n;
-		n0p[j] = (c0n + 3) & ~3;
-		n1p[j] = (NM - c0n + 3) & ~3;
-		ListEnt *Lj = lstp + j * NMP;
-		if (lane < 8) { // pads (never win a max); member slots are disjoint from them
-			ListEnt pe;
-			pe.v = NBL_NEG_INF;
-			pe.t = 0;
-			pe.tt = 0;
-			const int n1 = NM - c0n;
-			const int pos = (lane < 4) ? c0n + lane : n0p[j] + n1 + (lane - 4);
-			const bool need = (lane < 4) ? (c0n + lane < n0p[j]) : (n1 + lane - 4 < n1p[j]);
-			if (need) Lj[pos] = pe;
-		}
-		int base0 = 0, base1 = n0p[j];
-#pragma unroll
-		for (int i = 0; i < 4; i++) {
-			const int sym = TSYM(j, i);
-			const int pe_ = base0 + prefix_count(g0[i]), po_ = base1 + prefix_count(g1[i]);
-			const int pos = (sym & 1) ? po_ : pe_;
-			if (mem[j][i]) {
-				ListEnt e;
-				e.v = v[j][i];
-				e.t = sym;
-				e.tt = (sym & 0xFE) << 3;
-				Lj[pos] = e;
+			for (int i = 0; i < 4; i++) {
+				const int sym = TSYM(j, i);
+				const int pe_ = base0 + prefix_count(g0[i]), po_ = base1 + prefix_count(g1[i]);
+				const int pos = (sym & 1) ? po_ : pe_;
+				if (__builtin_amdgcn_inverse_ballot_w64(member[i])) {
+					ListEnt e;
+					e.v = v[j][i];
+					e.t = sym;
+					e.tt = (sym & 0xFE) << 3;
+					Lj[pos] = e;
+				}
+				base0 += __popcll(g0[i]);
+				base1 += __popcll(g1[i]);
 			}
-			base0 += __popcll(g0[i]);
-			base1 += __popcll(g1[i]);
 		}
 	}
 	__syncthreads();
