@@ -276,6 +276,58 @@ def test_full_size_round_trip(name, B):
     dec.close()
 
 
+def test_north_star_batch_equals_oracle_frame_by_frame(tmp_path, oracle):
+    """256 frames of the north-star configuration in the waterfall (Eb/N0 = 1 dB, ~45 % of the frames never converge), inputs
+    from the reference-compatible link chain: hard decisions, flags and iteration counts of EVERY frame -- converged or not --
+    must equal the oracle's canonical decode after 50 iterations (the oracle itself is pinned to the compiled reference)."""
+    from nbldpc_amd import hostlib
+    name = "divsalar.UNBLDPC.512.256.GF.256"
+    B = 256
+    hostlib.prepare_workdir(str(tmp_path), dict(gfq=256, code=name, method=2, max_iter=50, parallel=B, ems_nm=32, ems_nc=3,
+                                                constellation="BPSK", random_msg=1, seed=4242), name, "BPSK")
+    c = df.codes()[name]
+    L, tx, _, _ = hostlib.frontend(str(tmp_path), 1.0, 1, c["N"], c["N"] - c["M"], c["q"], B)
+    code = nb.Code(name)
+    dec = nb.Decoder(code, nb.METHOD_EMS, 50, ems_nm=32, ems_nc=3, poll_every=5)
+    out, conv, iters = dec.decode(L)
+    dec.close()
+    N, M, q, ev, ec, eh = df.code_edges(name)
+    ocode, ogf = oracle.Code(edges=(N, M, q, ev, ec, eh)), oracle.GF(q)
+    mk = lambda: oracle.Decoder(ocode, ogf, oracle.EMS, 50, oracle.CANONICAL, ems_nm=32, ems_nc=3)  # noqa: E731
+    o_out, o_conv, o_it = oracle.decode_batch(mk, L, nthreads=16)
+    assert np.array_equal(conv, o_conv) and np.array_equal(iters, o_it)
+    assert np.array_equal(out, o_out)
+    assert 0.2 < conv.mean() < 0.9  # the batch really straddles the waterfall
+    assert np.array_equal(out[conv == 1], tx[conv == 1])
+
+
+def test_reference_semantics_at_scale(tmp_path, oracle):
+    """GPU against the LITERAL oracle (bit-identical to the compiled reference, residue included) on 384 waterfall frames.
+    Required: identical convergence flags and iteration counts on every frame, identical hard decisions on every frame that
+    converges.  Frames that never converge are chaotic trajectories in which the reference's own order-dependent 1e-13
+    residue can flip an isolated symbol of the final hard decision: measured 1 symbol in 1 of 207 such
+    frames (512 frames, 1.0 dB) and none at 1.5 dB; the test bounds it at 4 symbols."""
+    from nbldpc_amd import hostlib
+    name = "divsalar.UNBLDPC.512.256.GF.256"
+    B = 384
+    hostlib.prepare_workdir(str(tmp_path), dict(gfq=256, code=name, method=2, max_iter=50, parallel=B, ems_nm=32, ems_nc=3,
+                                                constellation="BPSK", random_msg=1, seed=777), name, "BPSK")
+    c = df.codes()[name]
+    L, tx, _, _ = hostlib.frontend(str(tmp_path), 1.0, 1, c["N"], c["N"] - c["M"], c["q"], B)
+    code = nb.Code(name)
+    dec = nb.Decoder(code, nb.METHOD_EMS, 50, ems_nm=32, ems_nc=3, poll_every=5)
+    out, conv, iters = dec.decode(L)
+    dec.close()
+    N, M, q, ev, ec, eh = df.code_edges(name)
+    ocode, ogf = oracle.Code(edges=(N, M, q, ev, ec, eh)), oracle.GF(q)
+    mk = lambda: oracle.Decoder(ocode, ogf, oracle.EMS, 50, oracle.LITERAL, ems_nm=32, ems_nc=3)  # noqa: E731
+    l_out, l_conv, l_it = oracle.decode_batch(mk, L, nthreads=16)
+    assert np.array_equal(conv, l_conv) and np.array_equal(iters, l_it)
+    assert np.array_equal(out[conv == 1], l_out[conv == 1])
+    diff = int((out != l_out).sum())
+    assert diff <= 4, diff
+
+
 def test_device_pointer_entry_point():
     import torch
     g, meta = load_golden("cfg2_ems_u128")
