@@ -328,6 +328,38 @@ def test_reference_semantics_at_scale(tmp_path, oracle):
     assert diff <= 4, diff
 
 
+@pytest.mark.parametrize("name,code_name,cons,method,B,ebn0,iters,kw,rm", [
+    ("tems_bds", "BDS.576.288.GF.64", "GRAY_64QAM", 4, 48, 3.0, 50, dict(tems_nr=2, tems_nc=3), 0),
+    ("tems_gf16", "divsalar.UNBLDPC.128.64.GF.16", "BPSK", 4, 256, 2.0, 20, dict(tems_nr=2, tems_nc=2), 1),
+    ("bp_gf16", "divsalar.UNBLDPC.128.64.GF.16", "BPSK", 1, 256, 2.0, 20, dict(), 1),
+])
+def test_other_methods_frame_by_frame_at_scale(tmp_path, oracle, name, code_name, cons, method, B, ebn0, iters, kw, rm):
+    """T-EMS: the kernel's dynamic programme against the oracle's residue-free ENUMERATION, every frame (flags, iteration counts,
+    hard decisions).  BP: against the oracle's FP64 restatement (flags / iterations / decisions on converged frames; the
+    never-converging ones are compared symbol by symbol with a small allowance, exp/log differ in the last bit between libraries)."""
+    from nbldpc_amd import hostlib
+    c = df.codes()[code_name]
+    q = c["q"]
+    hostlib.prepare_workdir(str(tmp_path), dict(gfq=q, code=code_name, method=method, max_iter=iters, parallel=B, nqam=(2 if cons == "BPSK" else q),
+                                                constellation=cons, random_msg=rm, seed=99, **kw), code_name, cons)
+    L, tx, _, _ = hostlib.frontend(str(tmp_path), ebn0, 1, c["N"], c["N"] - c["M"], q, B)
+    code = nb.Code(code_name)
+    dec = nb.Decoder(code, method, iters, poll_every=5, **kw)
+    out, conv, its = dec.decode(L)
+    dec.close()
+    N, M, q, ev, ec, eh = df.code_edges(code_name)
+    ocode, ogf = oracle.Code(edges=(N, M, q, ev, ec, eh)), oracle.GF(q)
+    mk = lambda: oracle.Decoder(ocode, ogf, method, iters, oracle.CANONICAL, **kw)  # noqa: E731
+    o_out, o_conv, o_it = oracle.decode_batch(mk, L, nthreads=16)
+    assert np.array_equal(conv, o_conv) and np.array_equal(its, o_it)
+    assert np.array_equal(out[conv == 1], o_out[conv == 1])
+    if method == 4:
+        assert np.array_equal(out, o_out)
+    else:
+        assert int((out != o_out).sum()) <= 4
+    assert 0.05 < conv.mean() <= 1.0
+
+
 def test_device_pointer_entry_point():
     import torch
     g, meta = load_golden("cfg2_ems_u128")
