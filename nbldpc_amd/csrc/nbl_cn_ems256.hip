@@ -1,5 +1,5 @@
 // nbldpc_amd/csrc/nbl_cn_ems256.hip -- EMS check node specialised for the headline shape:
-//   GF(256), every check of degree 4, nc >= 3 (no deviation counting), nm in {8,16,32}.
+//   GF(256), every check of degree 4, any nc >= 1, nm in {8,16,32}.
 // (BASELINE configs 2 and 3: divsalar.UNBLDPC.{128.64,512.256}.GF.256, EMS nm=16/32.)
 //
 // Same arithmetic as cn_ems_kernel<256> (nbl_kernels.hip) -- the generic kernel is the readable statement of the
@@ -196,7 +196,9 @@ __device__ __forceinline__ void finish_members(SelState &s, int nm, uint64_t (&m
 // (a-posteriori sum L_ch + c2v_0 + c2v_1 in that order, hard decision, v2c = L_post - c2v, NBLDPC.cpp:808-823, 848-857) is
 // recomputed per edge from the previous iteration's c2v, so v2c never touches HBM; the wave that holds a variable's FIRST
 // edge writes its hard decision.  c2v is double-buffered (w.c2v_prev -> w.c2v) because the schedule is flooding.
-template <int NM, bool FUSED>
+// NC = min(nc, 3): 3 = no deviation counting needed (every other edge may deviate); 2 = at least one of the three other
+// edges stays at rank 0; 1 = conf(nm,1) is a subset of conf(q,1), nothing beyond the closed form is needed.
+template <int NM, bool FUSED, int NC>
 __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	constexpr int LOGNM = (NM == 8) ? 3 : (NM == 16) ? 4 : 5;
@@ -326,8 +328,8 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	// (a) a 64-bucket histogram of [lmin, mtop] (LDS atomics + DPP prefix sum) finds the bucket that holds the nm-th best
 	// value -- bucketing only has to be monotone, so its arithmetic needs no care; (b) a ballot quickselect, restricted to
 	// that bucket, finds the cut exactly; ties at the cut are resolved by symbol, higher first (:1731).
-	int n0[4], n0p[4], n1p[4];
-	{
+	int n0[4] = {0, 0, 0, 0}, n0p[4] = {0, 0, 0, 0}, n1p[4] = {0, 0, 0, 0};
+	if (NC >= 2) { // conf(nm,1) needs no lists: it is contained in conf(q,1)
 		int bk[4][4];
 		int *H = (int *)U; // [256 buckets][4 edges] (spans U and P); lane l reads buckets 4l .. 4l+3
 		{
@@ -464,25 +466,66 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 
 	// ---- conf(nm,nc >= 3): truncated max-plus convolutions; outputs 3,2 share P = e0 (+) e1 ----------------------
 	const int lane16 = lane << 4;
-	auto pair_conv = [&](int ja, int jb) {
+	// dst[t_a ^ t_b ^ sxor] = max over the nm x nm entry pairs of (v_a + bias) + v_b   (bias = 0: plain pair convolution)
+	auto pair_scatter = [&](double *dst, int ja, int jb, double bias, int sxor) {
 		__syncthreads();
 		double2 ninf;
 		ninf.x = NBL_NEG_INF;
 		ninf.y = NBL_NEG_INF;
-		((double2 *)P)[lane] = ninf;
-		((double2 *)P)[64 + lane] = ninf;
+		((double2 *)dst)[lane] = ninf;
+		((double2 *)dst)[64 + lane] = ninf;
 		// entry k of the contiguous member list lives at k (even group) or k - n0 + n0p (odd group) of the padded image
 		const int ka = lane & (NM - 1);
-		const ListEnt ea = lstp[ja * NMP + (ka < n0[ja] ? ka : ka - n0[ja] + n0p[ja])];
+		ListEnt ea = lstp[ja * NMP + (ka < n0[ja] ? ka : ka - n0[ja] + n0p[ja])];
+		ea.v = ea.v + bias;
+		ea.t ^= sxor;
 		__syncthreads();
 		constexpr int PER = 64 >> LOGNM, ROUNDS = (NM << LOGNM) >> 6;
 #pragma unroll
 		for (int it = 0; it < ROUNDS; it++) {
 			const int kb = it * PER + (lane >> LOGNM);
 			const ListEnt eb = lstp[jb * NMP + (kb < n0[jb] ? kb : kb - n0[jb] + n0p[jb])];
-			__hip_atomic_fetch_max(&P[ea.t ^ eb.t], ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			__hip_atomic_fetch_max(&dst[ea.t ^ eb.t], ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 		__syncthreads();
+	};
+	// same, accumulating into dst without clearing it
+	auto pair_scatter_more = [&](double *dst, int ja, int jb, double bias, int sxor) {
+		const int ka = lane & (NM - 1);
+		ListEnt ea = lstp[ja * NMP + (ka < n0[ja] ? ka : ka - n0[ja] + n0p[ja])];
+		ea.v = ea.v + bias;
+		ea.t ^= sxor;
+		constexpr int PER = 64 >> LOGNM, ROUNDS = (NM << LOGNM) >> 6;
+#pragma unroll
+		for (int it = 0; it < ROUNDS; it++) {
+			const int kb = it * PER + (lane >> LOGNM);
+			const ListEnt eb = lstp[jb * NMP + (kb < n0[jb] ? kb : kb - n0[jb] + n0p[jb])];
+			__hip_atomic_fetch_max(&dst[ea.t ^ eb.t], ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		__syncthreads();
+	};
+	auto pair_conv = [&](int ja, int jb) { pair_scatter(P, ja, jb, 0.0, 0); };
+	// Sout[s] = max(Sout[s], src[s ^ sx] + add) for the lane's four symbols
+	auto fold = [&](const double *src, int sx, double add, double (&Sout)[4]) {
+		const char *Sb = (const char *)src;
+		const int ad = lane16 ^ ((sx & 0xFE) << 3);
+		const double2 ra = *(const double2 *)(Sb + ad), rb = *(const double2 *)(Sb + (ad ^ 1024));
+		const bool sw = sx & 1;
+		Sout[0] = dmax(Sout[0], (sw ? ra.y : ra.x) + add);
+		Sout[1] = dmax(Sout[1], (sw ? ra.x : ra.y) + add);
+		Sout[2] = dmax(Sout[2], (sw ? rb.y : rb.x) + add);
+		Sout[3] = dmax(Sout[3], (sw ? rb.x : rb.y) + add);
+	};
+	// conf(nm,2) for output x with others o1 < o2 < o3 (P already holds o1 (+) o2): one of the three stays at rank 0 (:1769)
+	auto conf_nc2 = [&](int x, int o1, int o2, int o3) {
+		fold(P, ztop[o3], mtop[o3], S[x]);                                   // (v1 + v2) + m3
+		pair_scatter(U, o2, o3, mtop[o1], ztop[o1]);                         // (m1 + v2) + v3
+		pair_scatter_more(U, o1, o3, mtop[o2], ztop[o2]);                    // (v1 + m2) + v3
+		{
+			const double2 ra = ((const double2 *)U)[lane], rb = ((const double2 *)U)[64 + lane];
+			S[x][0] = dmax(S[x][0], ra.x); S[x][1] = dmax(S[x][1], ra.y);
+			S[x][2] = dmax(S[x][2], rb.x); S[x][3] = dmax(S[x][3], rb.y);
+		}
 	};
 	auto gather_conv = [&](int jc, double (&Sout)[4]) {
 		double a0 = NBL_NEG_INF, a1 = NBL_NEG_INF, a2 = NBL_NEG_INF, a3 = NBL_NEG_INF;
@@ -553,26 +596,54 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		dst[64 + lane] = o23;
 	};
 
-	pair_conv(0, 1);
-	STAMP(6);
-	gather_conv(2, S[3]);
-	gather_conv(3, S[2]);
-	STAMP(7);
-	emit(3);
-	emit(2);
-	STAMP(8);
-	pair_conv(0, 2);
-	STAMP(6);
-	gather_conv(3, S[1]);
-	STAMP(7);
-	emit(1);
-	STAMP(8);
-	pair_conv(1, 2);
-	STAMP(6);
-	gather_conv(3, S[0]);
-	STAMP(7);
-	emit(0);
-	STAMP(8);
+	if (NC >= 3) {
+		pair_conv(0, 1);
+		STAMP(6);
+		gather_conv(2, S[3]);
+		gather_conv(3, S[2]);
+		STAMP(7);
+		emit(3);
+		emit(2);
+		STAMP(8);
+		pair_conv(0, 2);
+		STAMP(6);
+		gather_conv(3, S[1]);
+		STAMP(7);
+		emit(1);
+		STAMP(8);
+		pair_conv(1, 2);
+		STAMP(6);
+		gather_conv(3, S[0]);
+		STAMP(7);
+		emit(0);
+		STAMP(8);
+	} else if (NC == 2) {
+		pair_conv(0, 1);
+		conf_nc2(3, 0, 1, 2);
+		STAMP(6);
+		emit(3);
+		STAMP(8);
+		conf_nc2(2, 0, 1, 3);
+		STAMP(6);
+		emit(2);
+		STAMP(8);
+		pair_conv(0, 2);
+		conf_nc2(1, 0, 2, 3);
+		STAMP(6);
+		emit(1);
+		STAMP(8);
+		pair_conv(1, 2);
+		conf_nc2(0, 1, 2, 3);
+		STAMP(6);
+		emit(0);
+		STAMP(8);
+	} else {
+		emit(3);
+		emit(2);
+		emit(1);
+		emit(0);
+		STAMP(8);
+	}
 
 	if (st_on && lane == 0) {
 		for (int i = 0; i < 12; i++) atomicAdd(&w.stamps[i], st_acc[i]);
@@ -584,10 +655,18 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 
 bool nbl_ems256_applicable(const NblGraphDev &g, bool all_dc4, int nm, int nc)
 {
-	return g.q == 256 && all_dc4 && nc >= 3 && (nm == 8 || nm == 16 || nm == 32);
+	return g.q == 256 && all_dc4 && nc >= 1 && (nm == 8 || nm == 16 || nm == 32);
 }
 
 size_t nbl_ems256_lds_bytes(int nm) { return 2 * Q * 8 + (size_t)4 * (nm + 8) * 16 + 16; }
+
+template <int NM, bool FUSED>
+static void launch_nc(int nc, dim3 grid, dim3 block, size_t lds, hipStream_t st, const NblGraphDev &g, const NblWork &w, const NblRun &r)
+{
+	if (nc >= 3) cn_ems_q256_dc4_kernel<NM, FUSED, 3><<<grid, block, lds, st>>>(g, w, r);
+	else if (nc == 2) cn_ems_q256_dc4_kernel<NM, FUSED, 2><<<grid, block, lds, st>>>(g, w, r);
+	else cn_ems_q256_dc4_kernel<NM, FUSED, 1><<<grid, block, lds, st>>>(g, w, r);
+}
 
 hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 {
@@ -595,16 +674,16 @@ hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const Nb
 	const size_t lds = nbl_ems256_lds_bytes(r.nm);
 	if (fused) {
 		switch (r.nm) {
-		case 8: cn_ems_q256_dc4_kernel<8, true><<<grid, block, lds, st>>>(g, w, r); break;
-		case 16: cn_ems_q256_dc4_kernel<16, true><<<grid, block, lds, st>>>(g, w, r); break;
-		case 32: cn_ems_q256_dc4_kernel<32, true><<<grid, block, lds, st>>>(g, w, r); break;
+		case 8: launch_nc<8, true>(r.nc, grid, block, lds, st, g, w, r); break;
+		case 16: launch_nc<16, true>(r.nc, grid, block, lds, st, g, w, r); break;
+		case 32: launch_nc<32, true>(r.nc, grid, block, lds, st, g, w, r); break;
 		default: return hipErrorInvalidValue;
 		}
 	} else {
 		switch (r.nm) {
-		case 8: cn_ems_q256_dc4_kernel<8, false><<<grid, block, lds, st>>>(g, w, r); break;
-		case 16: cn_ems_q256_dc4_kernel<16, false><<<grid, block, lds, st>>>(g, w, r); break;
-		case 32: cn_ems_q256_dc4_kernel<32, false><<<grid, block, lds, st>>>(g, w, r); break;
+		case 8: launch_nc<8, false>(r.nc, grid, block, lds, st, g, w, r); break;
+		case 16: launch_nc<16, false>(r.nc, grid, block, lds, st, g, w, r); break;
+		case 32: launch_nc<32, false>(r.nc, grid, block, lds, st, g, w, r); break;
 		default: return hipErrorInvalidValue;
 		}
 	}

@@ -175,21 +175,22 @@ def test_all_ties_and_erasures(oracle, codename, nm, nc):
     assert conv[1] == 1 and iters[1] == 1 and not out[1].any()
 
 
+@pytest.mark.parametrize("nc", [1, 2, 3])
 @pytest.mark.parametrize("nm", [8, 16, 32])
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_random_ties_all_kernel_variants(oracle, nm, seed):
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_ties_all_kernel_variants(oracle, nm, seed, nc):
     """Coarsely quantised random LLRs: hundreds of exact ties per vector, in the cut bucket of the top-nm selection, at rank 0
     and in the hard decisions.  Every sum is exact (small integers), so the reference's residue vanishes and the LITERAL oracle,
     the canonical oracle and all three GPU kernel variants must agree bit for bit on messages, decisions and iteration counts."""
     codename = "divsalar.UNBLDPC.128.64.GF.256"
     code = nb.Code(codename)
     N, M, q, ev, ec, eh = df.code_edges(codename)
-    rng = np.random.default_rng(100 * nm + seed)
+    rng = np.random.default_rng(100 * nm + 10 * nc + seed)
     B = 5
     L = np.round(rng.normal(-2, 3, (B, N, q - 1)))
     L[0] = np.round(rng.normal(-1, 1.2, (N, q - 1)))        # very few distinct values
     L[1, :, :] = np.where(rng.random((N, q - 1)) < 0.9, -3.0, 2.0)  # two-valued
-    kw = dict(ems_nm=nm, ems_nc=3, ems_factor=1.0, ems_offset=0.0)
+    kw = dict(ems_nm=nm, ems_nc=nc, ems_factor=1.0, ems_offset=0.0)
     ol = oracle.Decoder(oracle.Code(edges=(N, M, q, ev, ec, eh)), oracle.GF(q), oracle.EMS, 4, oracle.LITERAL, **kw)
     ref = []
     for b in range(B):

@@ -19,6 +19,7 @@ import nbldpc_amd as nb  # noqa: E402
 CFG = {
     "cfg2": dict(code="divsalar.UNBLDPC.128.64.GF.256", method=nb.METHOD_EMS, iters=50, batch=4096, kw=dict(ems_nm=16, ems_nc=3), D=0, ebn0=2.0, mod="bpsk"),
     "cfg3": dict(code="divsalar.UNBLDPC.512.256.GF.256", method=nb.METHOD_EMS, iters=50, batch=16384, kw=dict(ems_nm=32, ems_nc=3), D=0, ebn0=1.0, mod="bpsk"),
+    "cfg3nc2": dict(code="divsalar.UNBLDPC.512.256.GF.256", method=nb.METHOD_EMS, iters=50, batch=4096, kw=dict(ems_nm=32, ems_nc=2), D=0, ebn0=1.0, mod="bpsk"),
     "cfg4": dict(code="BDS.576.288.GF.64", method=nb.METHOD_TEMS, iters=50, batch=8192, kw=dict(tems_nr=2, tems_nc=3), D=1, ebn0=3.0, mod="qam"),
     "cfg5": dict(code="divsalar.CNBLDPC.512.256.GF.256", method=nb.METHOD_BP, iters=100, batch=1024, kw=dict(), D=1, ebn0=10.0, mod="qam"),
 }
