@@ -175,6 +175,37 @@ def test_all_ties_and_erasures(oracle, codename, nm, nc):
     assert conv[1] == 1 and iters[1] == 1 and not out[1].any()
 
 
+@pytest.mark.parametrize("nc", [1, 2, 3, 4])
+@pytest.mark.parametrize("nm", [8, 16, 32, 64])
+def test_every_shape_of_the_specialised_kernel_vs_oracle(oracle, nm, nc):
+    """Real-valued inputs, every (nm, nc) the GF(256) dc=4 fast path accepts (plus nm = 64 / which falls back to the generic
+    kernel): message state after 3 iterations bit-identical to the canonical oracle in all three kernel variants, shaped
+    outputs (factor / offset dead-zone) included."""
+    codename = "divsalar.UNBLDPC.128.64.GF.256"
+    code = nb.Code(codename)
+    N, M, q, ev, ec, eh = df.code_edges(codename)
+    rng = np.random.default_rng(1000 + 10 * nm + nc)
+    B = 6
+    L = rng.normal(-6, 7, (B, N, q - 1))
+    kw = dict(ems_nm=nm, ems_nc=nc, ems_factor=1.15, ems_offset=0.2)
+    od = oracle.Decoder(oracle.Code(edges=(N, M, q, ev, ec, eh)), oracle.GF(q), oracle.EMS, 3, oracle.CANONICAL, **kw)
+    ref = []
+    for b in range(B):
+        r, o, it = od.decode(L[b])
+        ref.append((r, o.copy(), it, [x.copy() for x in od.state()]))
+    for variant in (0, 1, 2):
+        dec = nb.Decoder(code, nb.METHOD_EMS, 3, **kw)
+        _force_generic(dec, variant)
+        dec.record_state(True)
+        out, conv, iters = dec.decode(L)
+        for b in range(B):
+            r, o, it, st = ref[b]
+            assert (conv[b], iters[b]) == (r, it) and np.array_equal(out[b], o), (variant, b)
+            P, V, Cc = dec.read_state(b)
+            assert np.array_equal(P, st[0]) and np.array_equal(V, st[1]) and np.array_equal(Cc, st[2]), (variant, b)
+        dec.close()
+
+
 @pytest.mark.parametrize("nc", [1, 2, 3])
 @pytest.mark.parametrize("nm", [8, 16, 32])
 @pytest.mark.parametrize("seed", [1, 2])
