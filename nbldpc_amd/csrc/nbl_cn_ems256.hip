@@ -7,13 +7,14 @@
 //   * lane l owns symbols {2l, 2l+1, 128+2l, 129+2l}: a q-vector is two 16-byte loads/stores per lane, and a
 //     max-plus XOR-gather "P[s ^ t]" is two conflict-free ds_read_b128 (natural layout, lane XOR only permutes the
 //     16-byte slots inside one 256-byte LDS row).
-//   * the four conf(q,1) result vectors stay in registers; one 2 KB LDS buffer per role (U, P, S) -> 9.5 KB per
-//     wave at nm = 32, four waves per SIMD.
+//   * the four conf(q,1) result vectors stay in registers; 2 KB LDS buffers U (also histogram / S staging) and P plus
+//     the packed lists -> 6.7 KB per wave at nm = 32, four waves per SIMD (VGPR-limited).
 //   * the nm-best lists are packed {value, symbol} 16-byte entries, split by bit 0 of the symbol so the pair swap
 //     of the gather is resolved by loop structure instead of per-element selects.
-//   * top-nm selection without sorting: a 64-bucket histogram (LDS atomics + DPP prefix sum) finds the bucket that
-//     holds the nm-th best value, a ballot quickselect inside that bucket finds the exact cut under SortLLRVector's
-//     order (value desc, higher symbol first among equals).
+//   * top-nm selection without sorting: a 256-bucket histogram (LDS atomics + DPP prefix sum) finds the bucket that
+//     holds the nm-th best value; if that bucket ends exactly at the nm-th entry the members are known, otherwise a ballot
+//     quickselect inside the bucket finds the exact cut under SortLLRVector's order (value desc, higher symbol first
+//     among equals).
 #include <hip/hip_runtime.h>
 #include "nbl_device.h"
 #include "nbl_kernels.h"
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	STAMP(1);
 
 	// ---- top-nm selection -------------------------------------------------------------------------------------------
-	// (a) a 64-bucket histogram of [lmin, mtop] (LDS atomics + DPP prefix sum) finds the bucket that holds the nm-th best
+	// (a) a 256-bucket histogram of [lmin, mtop] (LDS atomics + DPP prefix sum) finds the bucket that holds the nm-th best
 	// value -- bucketing only has to be monotone, so its arithmetic needs no care; (b) a ballot quickselect, restricted to
 	// that bucket, finds the cut exactly; ties at the cut are resolved by symbol, higher first (:1731).
 	int n0[4] = {0, 0, 0, 0}, n0p[4] = {0, 0, 0, 0}, n1p[4] = {0, 0, 0, 0};

@@ -1,10 +1,12 @@
 // nbldpc_amd/csrc/nbl_common.h -- shared host/device declarations of the MI355X decode path.
 //
 // HBM layout (all FP64, the reference's message precision):
-//   Lch [B][N][Qp]   channel LLRs, Qp = q rounded up... = q (slot a holds ln P(a)/P(0); slot 0 holds 0.0,
+//   Lch [B][N][q]    channel LLRs (slot a holds ln P(a)/P(0); slot 0 holds 0.0,
 //                    which is the reference's implicit "symbol 0 carries LLR 0", NBLDPC.cpp:1718)
-//   v2c [B][E][Qp]   variable-to-check messages, variable-major edge order  (L_v2c[col][d], NBLDPC.h:65)
-//   c2v [B][E][Qp]   check-to-variable messages, check-major edge order     (L_c2v[row][d], NBLDPC.h:66)
+//   v2c [B][E][q]    variable-to-check messages, variable-major edge order  (L_v2c[col][d], NBLDPC.h:65); absent on the
+//                    fused EMS path, where it is recomputed inside the check-node kernel
+//   c2v [B][E][q]    check-to-variable messages, check-major edge order     (L_c2v[row][d], NBLDPC.h:66); two buffers on
+//                    the fused path (flooding schedule: read iteration t-1, write iteration t)
 //   dec [B][N]       tentative hard decisions of the current iteration
 // A q-vector is one contiguous, 8*q-byte aligned run, so a wave streams it with fully coalesced loads.
 #pragma once
