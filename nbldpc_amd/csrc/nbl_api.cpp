@@ -309,7 +309,10 @@ static nbl_status launch_cn(nbl_decoder *d, const NblRun &r, hipStream_t st)
 		else HIP_TRY(d, nbl_launch_cn_ems(d->g, d->w, r, st));
 		break;
 	case NBL_METHOD_TEMS: HIP_TRY(d, nbl_launch_cn_tems(d->g, d->w, r, st)); break;
-	case NBL_METHOD_BP: HIP_TRY(d, nbl_launch_cn_bp(d->g, d->w, r, st)); break;
+	case NBL_METHOD_BP:
+		if (d->force_generic != 1 && nbl_bp256_applicable(d->g, d->all_dc4)) HIP_TRY(d, nbl_launch_cn_bp256(d->g, d->w, r, st));
+		else HIP_TRY(d, nbl_launch_cn_bp(d->g, d->w, r, st));
+		break;
 	default: d->err = "check-node kernel for this method is not built yet"; return NBL_ERR_UNSUPPORTED;
 	}
 	return NBL_OK;

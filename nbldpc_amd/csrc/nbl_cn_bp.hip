@@ -22,7 +22,7 @@
 //
 // Evaluation: each input is exponentiated ONCE (2Q exponentials per convolution instead of Q^2), the XOR convolution itself is
 // a sum of products (all terms positive: no cancellation), one logarithm per output.
-//   * narrow inputs (range(L1) + range(L2) < 600): plain doubles, e^(L-max), one FMA per term;
+//   * narrow inputs (min(range(L1), range(L2)) < 650): plain doubles, e^(L-max), one FMA per term;
 //   * wide inputs (LLRs thousands apart, e.g. high-order QAM at high SNR): every probability is kept as mantissa x 2^E with a
 //     separate 32-bit exponent, the running sum carries its own exponent (v_ldexp_f64 rescales exactly), so no term is ever
 //     lost to underflow -- the reference's log-domain formulation has unlimited range and so has this one.
@@ -42,7 +42,8 @@ __device__ __forceinline__ void lse_conv(const double *L1, const double *L2, dou
 		m1 = dmax(m1, __shfl_xor(m1, off, 64)); m2 = dmax(m2, __shfl_xor(m2, off, 64));
 		n1 = dmin(n1, __shfl_xor(n1, off, 64)); n2 = dmin(n2, __shfl_xor(n2, off, 64));
 	}
-	const bool narrow = (m1 - n1) + (m2 - n2) < 600.0; // wave-uniform
+	// every output has a term >= e^-min(range): with the smaller range below 650 nats whatever underflows is < 2^-76 of the result
+	const bool narrow = fmin(m1 - n1, m2 - n2) < 650.0; // wave-uniform
 	double lse[NS];
 	if (narrow) {
 		double *A = (double *)PA, *B = (double *)PB;

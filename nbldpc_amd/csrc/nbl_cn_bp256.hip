@@ -1,0 +1,230 @@
+// nbldpc_amd/csrc/nbl_cn_bp256.hip -- exact log-domain QSPA check node for GF(256), check degree 4 (BASELINE config 5):
+// NBLDPC.cpp:747-767, L_Back :1565, L_Forward :1593, LLR_BoxPlus :1621-1712.  Same mathematics as the generic kernel in
+// nbl_cn_bp.hip (check-domain XOR convolution in the log-sum-exp semiring, forward/backward partials computed once, six
+// convolutions per check), re-laid for the machine:
+//
+//   * one check per wave; lane l owns the four consecutive check-domain symbols 4l..4l+3 of every vector, so a 4x4 block of
+//     the XOR convolution  out[z] += A[x] * B[z ^ x]  (x = 4g..4g+3) needs four broadcast values of A and the four values of
+//     B at chunk l ^ g: 16 FMAs per two 16-byte LDS gathers instead of one LDS read per FMA;
+//   * every vector is held as probabilities relative to its own maximum, mantissa in [1,2] x 2^e with a separate 32-bit
+//     exponent, IN REGISTERS (12 VGPRs per vector); LDS holds only the two operands of the running convolution (6 KB per wave,
+//     the generic kernel needs 35 KB and runs one wave per SIMD);
+//   * narrow convolutions (the smaller of the two input ranges below 650 nats: every output then has a term >= e^-650, so
+//     whatever underflows is below 2^-76 of the result) run on plain doubles, one FMA per term;
+//   * wide convolutions (LLRs thousands of nats apart, the normal state after a few iterations of a converged frame) take
+//     the per-output top exponent first (integer max-plus pass), then one v_add3 + v_ldexp_f64 + v_fma_f64 per term: every
+//     term is scaled exactly, nothing is lost to underflow -- the reference's log-domain recursion has unlimited range and
+//     so has this.
+//
+// Numerics: as for the generic kernel, LLRs are not bit-identical to the reference's 80-bit long-double recursion (SURVEY 8c
+// hazard 3); parity is on hard decisions, flags and FER, LLRs within 1e-9 of the oracle's FP64 restatement.
+#include <hip/hip_runtime.h>
+#include "nbl_device.h"
+#include "nbl_kernels.h"
+
+namespace {
+
+constexpr int Q = 256;
+constexpr double LOG2E = 1.4426950408889634, LN2 = 0.6931471805599453;
+
+struct XVec {      // probabilities of the lane's four symbols relative to the vector's maximum
+	double m[4];   // mantissa in [1,2]
+	int e[4];      // exponent, <= 0, clamped at -1e9
+	double mx;     // wave-uniform: the maximum that was divided out (log domain)
+	double rng;    // wave-uniform: max - min (log domain)
+};
+
+__device__ __forceinline__ double wmax(double v)
+{
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) v = dmax(v, __shfl_xor(v, off, 64));
+	return v;
+}
+__device__ __forceinline__ double wmin(double v)
+{
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) v = dmin(v, __shfl_xor(v, off, 64));
+	return v;
+}
+
+__device__ __forceinline__ XVec to_xvec(const double (&L)[4])
+{
+	XVec r;
+	r.mx = wmax(dmax(dmax(L[0], L[1]), dmax(L[2], L[3])));
+	const double mn = wmin(dmin(dmin(L[0], L[1]), dmin(L[2], L[3])));
+	r.rng = r.mx - mn;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		const double y = dmax((L[i] - r.mx) * LOG2E, -1.0e9);
+		const double f = floor(y);
+		r.m[i] = exp2(y - f);
+		r.e[i] = (int)f;
+	}
+	return r;
+}
+
+struct Lds {
+	double2 *Am01, *Am23, *Bm01, *Bm23; // [64] mantissas (or plain probabilities) of symbols (4c, 4c+1) / (4c+2, 4c+3)
+	int4 *Ae, *Be;                      // [64] exponents of symbols 4c..4c+3
+};
+
+// out[z] = LSE_x(A[x] + B[z^x]) - LSE_x(A[x] + B[x]) for the lane's symbols z = 4 lane + i (log domain, out[0] = 0)
+__device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&out)[4], const Lds &s, int lane)
+{
+	const bool narrow = fmin(A.rng, B.rng) < 650.0; // wave-uniform
+	double lse[4];
+	if (narrow) {
+		s.Am01[lane] = make_double2(ldexp(A.m[0], A.e[0]), ldexp(A.m[1], A.e[1]));
+		s.Am23[lane] = make_double2(ldexp(A.m[2], A.e[2]), ldexp(A.m[3], A.e[3]));
+		s.Bm01[lane] = make_double2(ldexp(B.m[0], B.e[0]), ldexp(B.m[1], B.e[1]));
+		s.Bm23[lane] = make_double2(ldexp(B.m[2], B.e[2]), ldexp(B.m[3], B.e[3]));
+		__syncthreads();
+		double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+		for (int g = 0; g < 64; g++) {
+			const double2 a01 = s.Am01[g], a23 = s.Am23[g];
+			const double2 b01 = s.Bm01[lane ^ g], b23 = s.Bm23[lane ^ g];
+			const double a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y};
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+#pragma unroll
+				for (int i = 0; i < 4; i++) acc[i] = __fma_rn(a[j], b[i ^ j], acc[i]);
+		}
+#pragma unroll
+		for (int i = 0; i < 4; i++) lse[i] = (log(acc[i]) + A.mx) + B.mx;
+	} else {
+		s.Am01[lane] = make_double2(A.m[0], A.m[1]);
+		s.Am23[lane] = make_double2(A.m[2], A.m[3]);
+		s.Bm01[lane] = make_double2(B.m[0], B.m[1]);
+		s.Bm23[lane] = make_double2(B.m[2], B.m[3]);
+		s.Ae[lane] = make_int4(A.e[0], A.e[1], A.e[2], A.e[3]);
+		s.Be[lane] = make_int4(B.e[0], B.e[1], B.e[2], B.e[3]);
+		__syncthreads();
+		// top exponent of every output (the mantissa product is in [1,4], so every scaled term is <= 4)
+		int ex[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+#pragma unroll 2
+		for (int g = 0; g < 64; g++) {
+			const int4 av = s.Ae[g], bv = s.Be[lane ^ g];
+			const int ae[4] = {av.x, av.y, av.z, av.w}, be[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+#pragma unroll
+				for (int i = 0; i < 4; i++) ex[i] = max(ex[i], ae[j] + be[i ^ j]);
+		}
+		int nex[4];
+#pragma unroll
+		for (int i = 0; i < 4; i++) nex[i] = -ex[i];
+		double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+		for (int g = 0; g < 64; g++) {
+			const double2 a01 = s.Am01[g], a23 = s.Am23[g];
+			const double2 b01 = s.Bm01[lane ^ g], b23 = s.Bm23[lane ^ g];
+			const int4 av = s.Ae[g], bv = s.Be[lane ^ g];
+			const double a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y};
+			const int ae[4] = {av.x, av.y, av.z, av.w}, be[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					const int d = ae[j] + be[i ^ j] + nex[i]; // <= 0; exact power-of-two scaling, far below the range gives 0
+					acc[i] = __fma_rn(a[j], ldexp(b[i ^ j], d), acc[i]);
+				}
+		}
+#pragma unroll
+		for (int i = 0; i < 4; i++) lse[i] = ((log(acc[i]) + (double)ex[i] * LN2) + A.mx) + B.mx;
+	}
+	const double norm = read_lane_f64(lse[0], 0); // z = 0
+#pragma unroll
+	for (int i = 0; i < 4; i++) out[i] = lse[i] - norm;
+	if (lane == 0) out[0] = 0.0;
+	__syncthreads(); // operands are rewritten by the next convolution
+}
+
+__global__ __launch_bounds__(64) void cn_bp_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
+{
+	__shared__ __attribute__((aligned(16))) double smem[4 * Q]; // 8 KB: four permutation buffers, then the operands
+	const int lane = lane_id();
+	const int bid = blockIdx.x;
+	const int b = bid / g.M, m = bid % g.M;
+	if (!r.fixed_iters && w.done[b]) return;
+	const int c0 = g.coff[m];
+
+	const double *V = w.v2c + (size_t)b * g.E * Q;
+	double *C = w.c2v + ((size_t)b * g.E + c0) * Q;
+
+	// inputs into the check domain: p_d[h_d a] = v2c_d[a], symbol 0 = LLR 0 (the A1 == 0 branch of LLR_BoxPlus, :1623-1632)
+	GfMul<Q> mh[4];
+#pragma unroll
+	for (int d = 0; d < 4; d++) {
+		const double *Vd = V + (size_t)g.c_epos[c0 + d] * Q;
+		mh[d].init(g.c_h[c0 + d], g.poly, lane);
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int a = lane + 64 * i;
+			smem[d * Q + mh[d].at_slot(i)] = (a == 0) ? 0.0 : Vd[a];
+		}
+	}
+	__syncthreads();
+	XVec p[4];
+#pragma unroll
+	for (int d = 0; d < 4; d++) {
+		double L[4];
+#pragma unroll
+		for (int i = 0; i < 4; i++) L[i] = smem[d * Q + 4 * lane + i];
+		p[d] = to_xvec(L);
+	}
+	__syncthreads();
+
+	Lds s;
+	s.Am01 = (double2 *)smem;
+	s.Am23 = s.Am01 + 64;
+	s.Bm01 = s.Am23 + 64;
+	s.Bm23 = s.Bm01 + 64;
+	s.Ae = (int4 *)(s.Bm23 + 64);
+	s.Be = s.Ae + 64;
+	double *T = (double *)(s.Be + 64); // [Q] output staging (bytes 6144..8191)
+
+	auto emit = [&](const double (&o)[4], int d) {
+#pragma unroll
+		for (int i = 0; i < 4; i++) T[4 * lane + i] = o[i];
+		__syncthreads();
+		double *Cd = C + (size_t)d * Q;
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int a = lane + 64 * i;
+			Cd[a] = (a == 0) ? 0.0 : T[mh[d].at_slot(i)];
+		}
+		__syncthreads();
+	};
+
+	double o[4];
+	// forward: F2 = p0 [+] p1, F3 = F2 [+] p2 = output 3 (A2 == 0 case, :761-764); output 2 = F2 [+] p3
+	lse_conv(p[0], p[1], o, s, lane);
+	{
+		const XVec F2 = to_xvec(o);
+		lse_conv(F2, p[2], o, s, lane);
+		emit(o, 3);
+		lse_conv(F2, p[3], o, s, lane);
+		emit(o, 2);
+	}
+	// backward: R1 = p3 [+] p2, R0 = R1 [+] p1 = output 0 (A1 == 0 case, :757-760); output 1 = p0 [+] R1
+	lse_conv(p[3], p[2], o, s, lane);
+	{
+		const XVec R1 = to_xvec(o);
+		lse_conv(R1, p[1], o, s, lane);
+		emit(o, 0);
+		lse_conv(p[0], R1, o, s, lane);
+		emit(o, 1);
+	}
+}
+
+} // namespace
+
+bool nbl_bp256_applicable(const NblGraphDev &g, bool all_dc4) { return g.q == 256 && all_dc4; }
+
+hipError_t nbl_launch_cn_bp256(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
+{
+	dim3 grid((unsigned)((long long)r.B * g.M)), block(64);
+	cn_bp_q256_dc4_kernel<<<grid, block, 0, st>>>(g, w, r);
+	return hipGetLastError();
+}

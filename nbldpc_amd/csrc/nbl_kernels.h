@@ -21,3 +21,7 @@ hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const Nb
 // T-EMS and log-QSPA check nodes (nbl_cn_tems.hip, nbl_cn_bp.hip)
 hipError_t nbl_launch_cn_tems(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);
 hipError_t nbl_launch_cn_bp(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);
+
+// log-QSPA check node for GF(256), check degree 4 (nbl_cn_bp256.hip)
+bool nbl_bp256_applicable(const NblGraphDev &g, bool all_dc4);
+hipError_t nbl_launch_cn_bp256(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);
