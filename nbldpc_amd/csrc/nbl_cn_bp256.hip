@@ -25,6 +25,7 @@
 namespace {
 
 constexpr int Q = 256;
+constexpr int TOPK = 4;
 constexpr double LOG2E = 1.4426950408889634, LN2 = 0.6931471805599453;
 
 struct XVec {      // probabilities of the lane's four symbols relative to the vector's maximum
@@ -32,22 +33,52 @@ struct XVec {      // probabilities of the lane's four symbols relative to the v
 	int e[4];      // exponent, <= 0, clamped at -1e9
 	double mx;     // wave-uniform: the maximum that was divided out (log domain)
 	double rng;    // wave-uniform: max - min (log domain)
+	int tsym[TOPK], te[TOPK]; // wave-uniform: the TOPK most likely symbols and their exponents
 };
 
+// wave-wide reductions on the DPP network (row_shr 1,2,4,8, row_bcast 15, row_bcast 31; lane 63 holds the result)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_i32(int old, int v)
+{
+	return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_f64(double v)
+{
+	const int lo = dpp_i32<CTRL, ROW_MASK>(__double2loint(v), __double2loint(v));
+	const int hi = dpp_i32<CTRL, ROW_MASK>(__double2hiint(v), __double2hiint(v));
+	return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wmax(double v)
 {
-#pragma unroll
-	for (int off = 32; off >= 1; off >>= 1) v = dmax(v, __shfl_xor(v, off, 64));
-	return v;
+	v = dmax(v, dpp_f64<0x111, 0xF>(v));
+	v = dmax(v, dpp_f64<0x112, 0xF>(v));
+	v = dmax(v, dpp_f64<0x114, 0xF>(v));
+	v = dmax(v, dpp_f64<0x118, 0xF>(v));
+	v = dmax(v, dpp_f64<0x142, 0xA>(v));
+	v = dmax(v, dpp_f64<0x143, 0xC>(v));
+	return read_lane_f64(v, 63);
 }
 __device__ __forceinline__ double wmin(double v)
 {
-#pragma unroll
-	for (int off = 32; off >= 1; off >>= 1) v = dmin(v, __shfl_xor(v, off, 64));
-	return v;
+	v = dmin(v, dpp_f64<0x111, 0xF>(v));
+	v = dmin(v, dpp_f64<0x112, 0xF>(v));
+	v = dmin(v, dpp_f64<0x114, 0xF>(v));
+	v = dmin(v, dpp_f64<0x118, 0xF>(v));
+	v = dmin(v, dpp_f64<0x142, 0xA>(v));
+	v = dmin(v, dpp_f64<0x143, 0xC>(v));
+	return read_lane_f64(v, 63);
+}
+__device__ __forceinline__ int wmax_i32(int v)
+{
+	v = max(v, dpp_i32<0x111, 0xF>(v, v));
+	v = max(v, dpp_i32<0x112, 0xF>(v, v));
+	v = max(v, dpp_i32<0x114, 0xF>(v, v));
+	v = max(v, dpp_i32<0x118, 0xF>(v, v));
+	v = max(v, dpp_i32<0x142, 0xA>(v, v));
+	v = max(v, dpp_i32<0x143, 0xC>(v, v));
+	return __builtin_amdgcn_readlane(v, 63);
 }
 
-__device__ __forceinline__ XVec to_xvec(const double (&L)[4])
+__device__ __forceinline__ XVec to_xvec(const double (&L)[4], int lane)
 {
 	XVec r;
 	r.mx = wmax(dmax(dmax(L[0], L[1]), dmax(L[2], L[3])));
@@ -59,6 +90,21 @@ __device__ __forceinline__ XVec to_xvec(const double (&L)[4])
 		const double f = floor(y);
 		r.m[i] = exp2(y - f);
 		r.e[i] = (int)f;
+	}
+	// the TOPK largest entries (seeds of the per-output exponent estimate in lse_conv); ties in any order
+	int taken = 0;
+#pragma unroll
+	for (int k = 0; k < TOPK; k++) {
+		int key = -1;
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int ki = ((max(r.e[i], -(1 << 22)) + (1 << 22)) << 8) | (4 * lane + i);
+			key = ((taken >> i) & 1) ? key : max(key, ki);
+		}
+		const int best = wmax_i32(key);
+		r.tsym[k] = best & 255;
+		r.te[k] = (best >> 8) - (1 << 22);
+		if (key == best) taken |= 1 << (best & 3);
 	}
 	return r;
 }
@@ -100,35 +146,53 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 		s.Ae[lane] = make_int4(A.e[0], A.e[1], A.e[2], A.e[3]);
 		s.Be[lane] = make_int4(B.e[0], B.e[1], B.e[2], B.e[3]);
 		__syncthreads();
-		// top exponent of every output (the mantissa product is in [1,4], so every scaled term is <= 4)
+		// Reference exponent of every output.  The scaling below is exact for any reference that is within ~2^1000 of the
+		// output's largest term, so an estimate is enough: the largest term among the pairs that contain one of the TOPK
+		// entries of either operand (a lower bound of the true top).  If some term still overflows against it the exact top
+		// exponent is taken (integer max-plus pass) and the sum is redone.
 		int ex[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
-#pragma unroll 2
-		for (int g = 0; g < 64; g++) {
-			const int4 av = s.Ae[g], bv = s.Be[lane ^ g];
-			const int ae[4] = {av.x, av.y, av.z, av.w}, be[4] = {bv.x, bv.y, bv.z, bv.w};
+		const int *AeI = (const int *)s.Ae, *BeI = (const int *)s.Be;
 #pragma unroll
-			for (int j = 0; j < 4; j++)
+		for (int k = 0; k < TOPK; k++) {
 #pragma unroll
-				for (int i = 0; i < 4; i++) ex[i] = max(ex[i], ae[j] + be[i ^ j]);
+			for (int i = 0; i < 4; i++) {
+				const int z = 4 * lane + i;
+				ex[i] = max(ex[i], max(A.te[k] + BeI[z ^ A.tsym[k]], B.te[k] + AeI[z ^ B.tsym[k]]));
+			}
 		}
-		int nex[4];
+		double acc[4];
+		for (int attempt = 0;; attempt++) {
+			int nex[4];
 #pragma unroll
-		for (int i = 0; i < 4; i++) nex[i] = -ex[i];
-		double acc[4] = {0.0, 0.0, 0.0, 0.0};
+			for (int i = 0; i < 4; i++) { nex[i] = -ex[i]; acc[i] = 0.0; }
 #pragma unroll 2
-		for (int g = 0; g < 64; g++) {
-			const double2 a01 = s.Am01[g], a23 = s.Am23[g];
-			const double2 b01 = s.Bm01[lane ^ g], b23 = s.Bm23[lane ^ g];
-			const int4 av = s.Ae[g], bv = s.Be[lane ^ g];
-			const double a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y};
-			const int ae[4] = {av.x, av.y, av.z, av.w}, be[4] = {bv.x, bv.y, bv.z, bv.w};
+			for (int g = 0; g < 64; g++) {
+				const double2 a01 = s.Am01[g], a23 = s.Am23[g];
+				const double2 b01 = s.Bm01[lane ^ g], b23 = s.Bm23[lane ^ g];
+				const int4 av = s.Ae[g], bv = s.Be[lane ^ g];
+				const double a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y};
+				const int ae[4] = {av.x, av.y, av.z, av.w}, be[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-			for (int j = 0; j < 4; j++)
+				for (int j = 0; j < 4; j++)
 #pragma unroll
-				for (int i = 0; i < 4; i++) {
-					const int d = ae[j] + be[i ^ j] + nex[i]; // <= 0; exact power-of-two scaling, far below the range gives 0
-					acc[i] = __fma_rn(a[j], ldexp(b[i ^ j], d), acc[i]);
-				}
+					for (int i = 0; i < 4; i++) {
+						int d; // exact power-of-two scaling, far below the range gives 0
+						asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(ae[j]), "v"(be[i ^ j]), "v"(nex[i]));
+						acc[i] = __fma_rn(a[j], ldexp(b[i ^ j], d), acc[i]);
+					}
+			}
+			const bool fin = acc[0] < __builtin_huge_val() && acc[1] < __builtin_huge_val() && acc[2] < __builtin_huge_val() && acc[3] < __builtin_huge_val();
+			if (attempt || __all(fin)) break;
+			// exact top exponent of every output
+#pragma unroll 2
+			for (int g = 0; g < 64; g++) {
+				const int4 av = s.Ae[g], bv = s.Be[lane ^ g];
+				const int ae[4] = {av.x, av.y, av.z, av.w}, be[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+#pragma unroll
+					for (int i = 0; i < 4; i++) ex[i] = max(ex[i], ae[j] + be[i ^ j]);
+			}
 		}
 #pragma unroll
 		for (int i = 0; i < 4; i++) lse[i] = ((log(acc[i]) + (double)ex[i] * LN2) + A.mx) + B.mx;
@@ -171,7 +235,7 @@ __global__ __launch_bounds__(64) void cn_bp_q256_dc4_kernel(NblGraphDev g, NblWo
 		double L[4];
 #pragma unroll
 		for (int i = 0; i < 4; i++) L[i] = smem[d * Q + 4 * lane + i];
-		p[d] = to_xvec(L);
+		p[d] = to_xvec(L, lane);
 	}
 	__syncthreads();
 
@@ -201,7 +265,7 @@ __global__ __launch_bounds__(64) void cn_bp_q256_dc4_kernel(NblGraphDev g, NblWo
 	// forward: F2 = p0 [+] p1, F3 = F2 [+] p2 = output 3 (A2 == 0 case, :761-764); output 2 = F2 [+] p3
 	lse_conv(p[0], p[1], o, s, lane);
 	{
-		const XVec F2 = to_xvec(o);
+		const XVec F2 = to_xvec(o, lane);
 		lse_conv(F2, p[2], o, s, lane);
 		emit(o, 3);
 		lse_conv(F2, p[3], o, s, lane);
@@ -210,7 +274,7 @@ __global__ __launch_bounds__(64) void cn_bp_q256_dc4_kernel(NblGraphDev g, NblWo
 	// backward: R1 = p3 [+] p2, R0 = R1 [+] p1 = output 0 (A1 == 0 case, :757-760); output 1 = p0 [+] R1
 	lse_conv(p[3], p[2], o, s, lane);
 	{
-		const XVec R1 = to_xvec(o);
+		const XVec R1 = to_xvec(o, lane);
 		lse_conv(R1, p[1], o, s, lane);
 		emit(o, 0);
 		lse_conv(p[0], R1, o, s, lane);
