@@ -25,7 +25,7 @@
 namespace {
 
 constexpr int Q = 256;
-constexpr int TOPK = 4;
+constexpr int TOPK = 2;
 constexpr double LOG2E = 1.4426950408889634, LN2 = 0.6931471805599453;
 
 struct XVec {      // probabilities of the lane's four symbols relative to the vector's maximum
@@ -204,7 +204,7 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 	__syncthreads(); // operands are rewritten by the next convolution
 }
 
-__global__ __launch_bounds__(64) void cn_bp_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
+__global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	__shared__ __attribute__((aligned(16))) double smem[4 * Q]; // 8 KB: four permutation buffers, then the operands
 	const int lane = lane_id();
