@@ -308,7 +308,10 @@ static nbl_status launch_cn(nbl_decoder *d, const NblRun &r, hipStream_t st)
 		if (d->force_generic != 1 && nbl_ems256_applicable(d->g, d->all_dc4, r.nm, r.nc)) HIP_TRY(d, nbl_launch_cn_ems256(d->g, d->w, r, false, st));
 		else HIP_TRY(d, nbl_launch_cn_ems(d->g, d->w, r, st));
 		break;
-	case NBL_METHOD_TEMS: HIP_TRY(d, nbl_launch_cn_tems(d->g, d->w, r, st)); break;
+	case NBL_METHOD_TEMS:
+		if (d->force_generic != 1 && nbl_tems64_applicable(d->g, d->all_dc4, r.nr, r.nc)) HIP_TRY(d, nbl_launch_cn_tems64(d->g, d->w, r, st));
+		else HIP_TRY(d, nbl_launch_cn_tems(d->g, d->w, r, st));
+		break;
 	case NBL_METHOD_BP:
 		if (d->force_generic != 1 && nbl_bp256_applicable(d->g, d->all_dc4)) HIP_TRY(d, nbl_launch_cn_bp256(d->g, d->w, r, st));
 		else HIP_TRY(d, nbl_launch_cn_bp(d->g, d->w, r, st));

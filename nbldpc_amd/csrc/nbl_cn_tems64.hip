@@ -1,0 +1,211 @@
+// nbldpc_amd/csrc/nbl_cn_tems64.hip -- trellis-EMS check node for GF(64), check degree 4, nc <= 3 (BASELINE config 4):
+// NBLDPC.cpp:1055-1130, TEMS_Get_Beta :1789, TEMS_Get_deltaU :1814, TEMS_Get_Min :1836, TEMS_ConstructConf :1892.
+// Same arithmetic, same comparisons and the same tie rules as the general kernels in nbl_cn_tems.hip (whose header
+// explains why the min-plus dynamic programme over the columns equals the reference's path enumeration); what changes is
+// where the data lives:
+//
+//   * q = 64 = one delta-domain symbol per lane: the four trellis columns dU[d][lane], the column order, the candidate marks
+//     and all dynamic-programme states of the lane's check sum stay in registers;
+//   * layer 0 (no deviation) is the constant {0 at check sum 0}, so layer 1 (one deviating column) is a per-lane minimum
+//     over the marked columns -- no convolution; only layers 2 and 3 gather a predecessor state `S[s ^ q]` from LDS, and
+//     they read just the 24 bytes they need (cost and path code of layers 1, 2) instead of a 48-byte record;
+//   * candidate lists are compacted with ballots (no LDS atomics), the four outputs are formed together (3 barriers instead
+//     of 12), wave reductions run on the DPP network.
+#include <hip/hip_runtime.h>
+#include "nbl_device.h"
+#include "nbl_kernels.h"
+
+namespace {
+
+constexpr int Q = 64, P = 6, DC = 4;
+
+struct __attribute__((aligned(16))) Cand { double u; int q; int pad; };
+
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_f64(double v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+	const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wmax(double v)
+{
+	v = dmax(v, dpp_f64<0x111, 0xF>(v)); // row_shr 1, 2, 4, 8: lane 15 of every row holds the row maximum
+	v = dmax(v, dpp_f64<0x112, 0xF>(v));
+	v = dmax(v, dpp_f64<0x114, 0xF>(v));
+	v = dmax(v, dpp_f64<0x118, 0xF>(v));
+	v = dmax(v, dpp_f64<0x142, 0xA>(v)); // row_bcast15 into rows 1, 3
+	v = dmax(v, dpp_f64<0x143, 0xC>(v)); // row_bcast31 into rows 2, 3
+	return read_lane_f64(v, 63);
+}
+
+// smaller cost wins, equal cost: smaller path code (= earlier in the reference's enumeration order)
+__device__ __forceinline__ void relax(double &bv, unsigned &bc, double val, unsigned code)
+{
+	const bool lt = val < bv;
+	bv = lt ? val : bv;
+	bc = lt ? code : bc;
+	const unsigned cm = code < bc ? code : bc;
+	bc = (val == bv) ? cm : bc;
+}
+
+__device__ __forceinline__ double pick(const double (&u)[DC], int k)
+{
+	return k == 0 ? u[0] : k == 1 ? u[1] : k == 2 ? u[2] : u[3];
+}
+
+__global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
+{
+	__shared__ double dU[DC][Q];                            // delta-domain trellis (:1814-1834)
+	__shared__ double Lc[DC][Q];                            // extrinsic minima of every output edge (:1075-1102)
+	__shared__ __attribute__((aligned(16))) double2 Sv[Q];  // cost of layers 1, 2 of every check sum before the current column
+	__shared__ uint2 Sc[Q];                                 // their path codes
+	__shared__ __attribute__((aligned(16))) Cand cl[DC][Q + 4];
+	const int lane = lane_id();
+	const int b = blockIdx.x / g.M, m = blockIdx.x % g.M;
+	if (!r.fixed_iters && w.done[b]) return;
+	const int c0 = g.coff[m];
+	const int nr = r.nr, nc = r.nc;
+	const double *V = w.v2c + (size_t)b * g.E * Q;
+	double *C = w.c2v + ((size_t)b * g.E + c0) * Q;
+
+	// ---- 1. beta, syndrome, dU -------------------------------------------------------------------------------------------
+	int beta[DC], hmul[DC], syn = 0;
+#pragma unroll
+	for (int d = 0; d < DC; d++) {
+		const double *Vd = V + (size_t)g.c_epos[c0 + d] * Q;
+		const double v = lane > 0 ? Vd[lane] : 0.0;
+		// most reliable symbol: strict '>' over ascending symbols from a running maximum of 0 (:1798-1807) = the lowest symbol
+		// that holds the maximum of {0, v[1..]}; symbol 0 (value 0) when nothing is positive
+		const double mx = wmax(v);
+		const uint64_t top = __ballot(v == mx);
+		const int arg = top ? __builtin_ctzll(top) : 0;
+		GfMul<Q> mh;
+		mh.init(g.c_h[c0 + d], g.poly, lane);
+		int bd = 0;
+#pragma unroll
+		for (int k = 0; k < P; k++) bd ^= ((arg >> k) & 1) ? mh.basis[k] : 0; // beta_d = h * argmax
+		bd = uniform(bd);
+		beta[d] = bd;
+		syn ^= bd;
+		hmul[d] = mh.at_slot(0);
+		dU[d][hmul[d] ^ bd] = mx - v; // dU[d][h a ^ beta] = Lmax - L(a), L(0) = 0 (:1826-1831)
+	}
+	__syncthreads();
+	double u[DC];
+#pragma unroll
+	for (int d = 0; d < DC; d++) u[d] = dU[d][lane];
+
+	// ---- 2. stable ascending order of the four columns per symbol, the nr smallest marked (:1836-1890) --------------------
+	int mask = 0, o0 = 0, o1 = 0;
+#pragma unroll
+	for (int d = 0; d < DC; d++) {
+		int rank = 0;
+#pragma unroll
+		for (int e = 0; e < DC; e++)
+			if (e != d) rank += (u[e] < u[d] || (u[e] == u[d] && e < d)) ? 1 : 0;
+		mask |= (rank < nr) ? (1 << d) : 0;
+		o0 = (rank == 0) ? d : o0;
+		o1 = (rank == 1) ? d : o1;
+	}
+	// deviation candidates per column: non-zero symbols only (symbol 0 = "no deviation"), ascending symbol order
+	int n4[DC];
+#pragma unroll
+	for (int d = 0; d < DC; d++) {
+		const bool c = ((mask >> d) & 1) && lane > 0;
+		const uint64_t bal = __ballot(c);
+		const int n = uniform(__builtin_popcountll(bal));
+		if (c) {
+			Cand e;
+			e.u = u[d];
+			e.q = lane;
+			e.pad = 0;
+			cl[d][prefix_count(bal)] = e;
+		}
+		n4[d] = (n + 3) & ~3;
+		if (lane < 4 && n + lane < n4[d]) { // pad to a multiple of four with entries that can never win
+			Cand e;
+			e.u = __builtin_huge_val();
+			e.q = 0;
+			e.pad = 0;
+			cl[d][n + lane] = e;
+		}
+	}
+
+	// ---- 3. min-plus dynamic programme over the columns; v[l], c[l] = best path with exactly l deviating columns -----------
+	const double INF = __builtin_huge_val();
+	double v1 = INF, v2 = INF, v3 = INF;
+	unsigned c1 = 0, c2 = 0, c3 = 0;
+	if (((mask >> 0) & 1) && lane > 0) { v1 = u[0]; c1 = (unsigned)lane << (P * (DC - 1)); }
+#pragma unroll
+	for (int d = 1; d < DC; d++) {
+		const int sh = P * (DC - 1 - d); // digit of column d in the path code
+		Sv[lane] = make_double2(v1, v2);
+		Sc[lane] = make_uint2(c1, c2);
+		__syncthreads();
+		if (nc >= 2) {
+			for (int k = 0; k < n4[d]; k += 4) {
+				Cand e[4];
+#pragma unroll
+				for (int t = 0; t < 4; t++) e[t] = cl[d][k + t]; // LDS broadcast
+#pragma unroll
+				for (int t = 0; t < 4; t++) {
+					const double2 sv = Sv[lane ^ e[t].q];
+					const uint2 sc = Sc[lane ^ e[t].q];
+					const unsigned dig = (unsigned)e[t].q << sh;
+					relax(v2, c2, sv.x + e[t].u, sc.x + dig);
+					if (d >= 2 && nc >= 3) relax(v3, c3, sv.y + e[t].u, sc.y + dig);
+				}
+			}
+		}
+		if (((mask >> d) & 1) && lane > 0) relax(v1, c1, u[d], (unsigned)lane << sh);
+		__syncthreads();
+	}
+	// dW, Eta: best layer of the lane's check sum
+	double dW = INF;
+	unsigned eta = 0xffffffffu;
+	{
+		const double v0 = lane == 0 ? 0.0 : INF;
+		if (v0 < dW || (v0 == dW && 0u < eta)) { dW = v0; eta = 0u; }
+		if (nc >= 1 && (v1 < dW || (v1 == dW && c1 < eta))) { dW = v1; eta = c1; }
+		if (nc >= 2 && (v2 < dW || (v2 == dW && c2 < eta))) { dW = v2; eta = c2; }
+		if (nc >= 3 && (v3 < dW || (v3 == dW && c3 < eta))) { dW = v3; eta = c3; }
+	}
+
+	// ---- 4. outputs of the four edges --------------------------------------------------------------------------------------
+#pragma unroll
+	for (int d = 0; d < DC; d++) Lc[d][lane] = NBL_DBL_MAX;
+	__syncthreads();
+#pragma unroll
+	for (int d = 0; d < DC; d++) {
+		const int dev = (int)((eta >> (P * (DC - 1 - d))) & (Q - 1));
+		const double cand = dW - dU[d][dev]; // :1088
+		__hip_atomic_fetch_min(&Lc[d][lane ^ dev], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+	__syncthreads();
+#pragma unroll
+	for (int d = 0; d < DC; d++)
+		if (Lc[d][lane] == NBL_DBL_MAX) Lc[d][lane] = (d == o0) ? pick(u, o1) : pick(u, o0); // never reached (:1095-1102)
+	__syncthreads();
+#pragma unroll
+	for (int d = 0; d < DC; d++) {
+		// delta domain -> LLR, un-permute by h (:1105-1127)
+		const int bsyn = syn ^ beta[d];
+		const double L0 = -1.0 * Lc[d][bsyn];
+		const int e = hmul[d] ^ bsyn; // eta with h^-1 (eta ^ bsyn) = lane
+		C[(size_t)d * Q + lane] = (lane == 0) ? 0.0 : shape_llr(-1.0 * Lc[d][e] - L0, r.factor, r.offset);
+	}
+}
+
+} // namespace
+
+bool nbl_tems64_applicable(const NblGraphDev &g, bool all_dc4, int nr, int nc)
+{
+	return g.q == 64 && all_dc4 && nc >= 1 && nc <= 3 && nr >= 1 && nr <= 4;
+}
+
+hipError_t nbl_launch_cn_tems64(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
+{
+	dim3 grid((unsigned)((long long)r.B * g.M)), block(64);
+	cn_tems_q64_dc4_kernel<<<grid, block, 0, st>>>(g, w, r);
+	return hipGetLastError();
+}
