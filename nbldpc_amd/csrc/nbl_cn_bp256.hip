@@ -36,53 +36,11 @@ struct XVec {      // probabilities of the lane's four symbols relative to the v
 	int tsym[TOPK], te[TOPK]; // wave-uniform: the TOPK most likely symbols and their exponents
 };
 
-// wave-wide reductions on the DPP network (row_shr 1,2,4,8, row_bcast 15, row_bcast 31; lane 63 holds the result)
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_i32(int old, int v)
-{
-	return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
-}
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_f64(double v)
-{
-	const int lo = dpp_i32<CTRL, ROW_MASK>(__double2loint(v), __double2loint(v));
-	const int hi = dpp_i32<CTRL, ROW_MASK>(__double2hiint(v), __double2hiint(v));
-	return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wmax(double v)
-{
-	v = dmax(v, dpp_f64<0x111, 0xF>(v));
-	v = dmax(v, dpp_f64<0x112, 0xF>(v));
-	v = dmax(v, dpp_f64<0x114, 0xF>(v));
-	v = dmax(v, dpp_f64<0x118, 0xF>(v));
-	v = dmax(v, dpp_f64<0x142, 0xA>(v));
-	v = dmax(v, dpp_f64<0x143, 0xC>(v));
-	return read_lane_f64(v, 63);
-}
-__device__ __forceinline__ double wmin(double v)
-{
-	v = dmin(v, dpp_f64<0x111, 0xF>(v));
-	v = dmin(v, dpp_f64<0x112, 0xF>(v));
-	v = dmin(v, dpp_f64<0x114, 0xF>(v));
-	v = dmin(v, dpp_f64<0x118, 0xF>(v));
-	v = dmin(v, dpp_f64<0x142, 0xA>(v));
-	v = dmin(v, dpp_f64<0x143, 0xC>(v));
-	return read_lane_f64(v, 63);
-}
-__device__ __forceinline__ int wmax_i32(int v)
-{
-	v = max(v, dpp_i32<0x111, 0xF>(v, v));
-	v = max(v, dpp_i32<0x112, 0xF>(v, v));
-	v = max(v, dpp_i32<0x114, 0xF>(v, v));
-	v = max(v, dpp_i32<0x118, 0xF>(v, v));
-	v = max(v, dpp_i32<0x142, 0xA>(v, v));
-	v = max(v, dpp_i32<0x143, 0xC>(v, v));
-	return __builtin_amdgcn_readlane(v, 63);
-}
-
 __device__ __forceinline__ XVec to_xvec(const double (&L)[4], int lane)
 {
 	XVec r;
-	r.mx = wmax(dmax(dmax(L[0], L[1]), dmax(L[2], L[3])));
-	const double mn = wmin(dmin(dmin(L[0], L[1]), dmin(L[2], L[3])));
+	r.mx = wave_fmax(dmax(dmax(L[0], L[1]), dmax(L[2], L[3])));
+	const double mn = wave_fmin(dmin(dmin(L[0], L[1]), dmin(L[2], L[3])));
 	r.rng = r.mx - mn;
 #pragma unroll
 	for (int i = 0; i < 4; i++) {
@@ -101,7 +59,7 @@ __device__ __forceinline__ XVec to_xvec(const double (&L)[4], int lane)
 			const int ki = ((max(r.e[i], -(1 << 22)) + (1 << 22)) << 8) | (4 * lane + i);
 			key = ((taken >> i) & 1) ? key : max(key, ki);
 		}
-		const int best = wmax_i32(key);
+		const int best = wave_imax(key);
 		r.tsym[k] = best & 255;
 		r.te[k] = (best >> 8) - (1 << 22);
 		if (key == best) taken |= 1 << (best & 3);

@@ -21,23 +21,6 @@ constexpr int Q = 64, P = 6, DC = 4;
 
 struct __attribute__((aligned(16))) Cand { double u; int q; int pad; };
 
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_f64(double v)
-{
-	const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xF, false);
-	const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
-	return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wmax(double v)
-{
-	v = dmax(v, dpp_f64<0x111, 0xF>(v)); // row_shr 1, 2, 4, 8: lane 15 of every row holds the row maximum
-	v = dmax(v, dpp_f64<0x112, 0xF>(v));
-	v = dmax(v, dpp_f64<0x114, 0xF>(v));
-	v = dmax(v, dpp_f64<0x118, 0xF>(v));
-	v = dmax(v, dpp_f64<0x142, 0xA>(v)); // row_bcast15 into rows 1, 3
-	v = dmax(v, dpp_f64<0x143, 0xC>(v)); // row_bcast31 into rows 2, 3
-	return read_lane_f64(v, 63);
-}
-
 // smaller cost wins, equal cost: smaller path code (= earlier in the reference's enumeration order)
 __device__ __forceinline__ void relax(double &bv, unsigned &bc, double val, unsigned code)
 {
@@ -76,7 +59,7 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 		const double v = lane > 0 ? Vd[lane] : 0.0;
 		// most reliable symbol: strict '>' over ascending symbols from a running maximum of 0 (:1798-1807) = the lowest symbol
 		// that holds the maximum of {0, v[1..]}; symbol 0 (value 0) when nothing is positive
-		const double mx = wmax(v);
+		const double mx = wave_fmax(v);
 		const uint64_t top = __ballot(v == mx);
 		const int arg = top ? __builtin_ctzll(top) : 0;
 		GfMul<Q> mh;

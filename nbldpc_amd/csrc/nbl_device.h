@@ -35,6 +35,48 @@ __device__ __forceinline__ double read_lane_f64(double v, int lane)
 	return __hiloint2double(hi, lo);
 }
 
+// wave-wide reductions on the DPP network: row_shr 1, 2, 4, 8 leave the row result in lane 15 of every row, row_bcast15 /
+// row_bcast31 carry it across the rows; lane 63 holds the wave result.  Lanes without a source keep their own value, which is
+// neutral for max / min.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_i32(int v)
+{
+	return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_f64(double v)
+{
+	return __hiloint2double(dpp_i32<CTRL, ROW_MASK>(__double2hiint(v)), dpp_i32<CTRL, ROW_MASK>(__double2loint(v)));
+}
+__device__ __forceinline__ double wave_fmax(double v)
+{
+	v = dmax(v, dpp_f64<0x111, 0xF>(v));
+	v = dmax(v, dpp_f64<0x112, 0xF>(v));
+	v = dmax(v, dpp_f64<0x114, 0xF>(v));
+	v = dmax(v, dpp_f64<0x118, 0xF>(v));
+	v = dmax(v, dpp_f64<0x142, 0xA>(v));
+	v = dmax(v, dpp_f64<0x143, 0xC>(v));
+	return read_lane_f64(v, 63);
+}
+__device__ __forceinline__ double wave_fmin(double v)
+{
+	v = dmin(v, dpp_f64<0x111, 0xF>(v));
+	v = dmin(v, dpp_f64<0x112, 0xF>(v));
+	v = dmin(v, dpp_f64<0x114, 0xF>(v));
+	v = dmin(v, dpp_f64<0x118, 0xF>(v));
+	v = dmin(v, dpp_f64<0x142, 0xA>(v));
+	v = dmin(v, dpp_f64<0x143, 0xC>(v));
+	return read_lane_f64(v, 63);
+}
+__device__ __forceinline__ int wave_imax(int v)
+{
+	v = max(v, dpp_i32<0x111, 0xF>(v));
+	v = max(v, dpp_i32<0x112, 0xF>(v));
+	v = max(v, dpp_i32<0x114, 0xF>(v));
+	v = max(v, dpp_i32<0x118, 0xF>(v));
+	v = max(v, dpp_i32<0x142, 0xA>(v));
+	v = max(v, dpp_i32<0x143, 0xC>(v));
+	return __builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ double uniform_f64(double v)
@@ -84,19 +126,17 @@ template <int Q> struct GfMul {
 template <int NS> __device__ __forceinline__ int wave_decide(const double (&v)[NS], int lane, int q)
 {
 	double best = 0.0;
+#pragma unroll
+	for (int i = 0; i < NS; i++)
+		if (lane + 64 * i < q) best = dmax(best, v[i]);
+	const double mx = wave_fmax(best);
 	int arg = 0;
 #pragma unroll
-	for (int i = 0; i < NS; i++) {
-		int a = lane + 64 * i;
-		if (a < q && v[i] > best) { best = v[i]; arg = a; }
+	for (int i = NS - 1; i >= 0; i--) { // the lowest symbol that holds the maximum: lowest slot first, then lowest lane
+		const uint64_t hit = __ballot(lane + 64 * i < q && v[i] == mx);
+		arg = hit ? 64 * i + __builtin_ctzll(hit) : arg;
 	}
-#pragma unroll
-	for (int off = 32; off >= 1; off >>= 1) {
-		double ob = __shfl_xor(best, off, 64);
-		int oa = __shfl_xor(arg, off, 64);
-		if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
-	}
-	return arg;
+	return mx > 0.0 ? arg : 0;
 }
 
 // check-to-variable shaping, NBLDPC.cpp:903-916 / 1113-1126
