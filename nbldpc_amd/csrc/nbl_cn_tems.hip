@@ -13,7 +13,10 @@
 //     check sum as the path with both set to 0, whose cost is not larger (every dU >= 0, fl(x+u) is monotone) and which
 //     comes earlier in enumeration order, so a duplicate path never sets dW or Eta;
 //   * enumeration order is lexicographic in (q_0 .. q_dc-1), so "first strict minimum" = smallest (cost, path code);
-//   * costs are left-to-right sums (((0+u0)+u1)+u2).., and min commutes with the rounded add.
+//   * costs are left-to-right sums (((0+u0)+u1)+u2).., and min commutes with the rounded add.  (The one case a dynamic
+//     programme cannot follow: two prefixes whose costs differ by an ulp and whose extensions round to the SAME sum -- the
+//     reference then keeps the path that comes first in enumeration order, the programme the one with the cheaper prefix.
+//     dW is identical, Eta may differ.  It takes manufactured inputs (tests/test_gpu_parity.py) to see it.)
 // The residue of the reference's running add/subtract (sumNonLLR += / -=, :1917/:1921) is not reproduced.
 #include <hip/hip_runtime.h>
 #include "nbl_device.h"

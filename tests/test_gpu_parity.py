@@ -240,11 +240,102 @@ def test_random_ties_all_kernel_variants(oracle, nm, seed, nc):
         dec.close()
 
 
+@pytest.mark.parametrize("nr,nc", [(1, 1), (2, 1), (2, 2), (2, 3), (3, 2), (3, 3), (4, 3)])
+def test_tems_gf64_every_shape_ties_and_erasures_vs_oracle(oracle, nr, nc):
+    """GF(64) dc=4 T-EMS kernel (and the general kernel beside it), every (nr, nc) it accepts, state after 3 iterations
+    bit-identical to the oracle:
+      * real-valued frames (one with erased symbols, one all-zero) with shaped outputs (factor, offset dead-zone);
+      * integer-valued frames with factor 1 / offset 0: hundreds of EXACT ties per check (column order strict '<' :1858, first
+        strict minimum :1926, path-code tie-break) and exact arithmetic throughout (damping weights 1/4, 3/4), so the reference's
+        running-sum residue vanishes and the LITERAL restatement must agree as well.
+    Integer inputs are not combined with a factor like 1.1: that manufactures path costs one ulp apart (2 vs 1.9999999999999998)
+    whose sums round to the same value, the one case where a dynamic programme and the reference's enumeration can pick
+    different (equal-cost) paths -- DESIGN.md section 3."""
+    codename = "BDS.576.288.GF.64"
+    code = nb.Code(codename)
+    N, M, q, ev, ec, eh = df.code_edges(codename)
+    rng = np.random.default_rng(640 + 10 * nr + nc)
+    mk = lambda mode, k: oracle.Decoder(oracle.Code(edges=(N, M, q, ev, ec, eh)), oracle.GF(q), oracle.TEMS, 3, mode, **k)  # noqa: E731
+
+    def run(L, kw, modes):
+        refs = []
+        for mode in modes:
+            od = mk(mode, kw)
+            ref = []
+            for b in range(L.shape[0]):
+                r, o, it = od.decode(L[b])
+                ref.append((r, o.copy(), it, [x.copy() for x in od.state()]))
+            refs.append(ref)
+        for variant in (0, 1):
+            dec = nb.Decoder(code, nb.METHOD_TEMS, 3, **kw)
+            _force_generic(dec, variant)
+            dec.record_state(True)
+            out, conv, iters = dec.decode(L)
+            for ref in refs:
+                for b in range(L.shape[0]):
+                    r, o, it, st = ref[b]
+                    assert (conv[b], iters[b]) == (r, it) and np.array_equal(out[b], o), (variant, b)
+                    P, V, Cc = dec.read_state(b)
+                    assert np.array_equal(P, st[0]) and np.array_equal(V, st[1]) and np.array_equal(Cc, st[2]), (variant, b)
+            dec.close()
+
+    Lr = rng.normal(-4, 5, (3, N, q - 1))
+    Lr[1, ::3] = 0.0                                    # erased symbols
+    Lr[2] = 0.0                                         # everything ties
+    run(Lr, dict(tems_nr=nr, tems_nc=nc, tems_factor=1.1, tems_offset=0.15), [oracle.CANONICAL])
+    Li = np.round(rng.normal(-1, 2, (3, N, q - 1)))     # integer-valued: exact ties everywhere
+    Li[1] = np.where(rng.random((N, q - 1)) < 0.8, -2.0, 3.0)
+    Li[2, ::2] = 0.0
+    run(Li, dict(tems_nr=nr, tems_nc=nc, tems_factor=1.0, tems_offset=0.0), [oracle.CANONICAL, oracle.LITERAL])
+
+
+def test_bp_gf256_wide_ranges_and_exponent_fallback(oracle):
+    """GF(256) dc=4 log-QSPA kernel on inputs that leave the narrow path: LLRs thousands of nats apart (mantissa/exponent
+    path), and vectors with three near-top symbols over a floor at -4000, for which the two-entry estimate of the output
+    exponents is ~2^5700 too low, so the exact max-plus pass must take over.  The oracle's long-double recursion has no range
+    limit; state after 2 iterations within 1e-9 (relative to the largest magnitude), decisions equal, and the general kernel
+    agrees as well."""
+    codename = "divsalar.CNBLDPC.512.256.GF.256"
+    code = nb.Code(codename)
+    N, M, q, ev, ec, eh = df.code_edges(codename)
+    rng = np.random.default_rng(256)
+    B = 3
+    L = np.empty((B, N, q - 1))
+    L[0] = rng.normal(-300, 250, (N, q - 1))                    # wide: ranges of ~1500 nats
+    L[1] = rng.normal(-20, 10, (N, q - 1))                      # narrow
+    L[2] = -4000.0 + rng.normal(0, 30, (N, q - 1))              # floor
+    for n in range(N):                                          # symbol 0 (LLR 0) and two more near the top
+        a = rng.choice(q - 1, 2, replace=False)
+        L[2, n, a[0]] = 1.0 + rng.random()                 # positive: non-zero decisions, the frame does not stop at iteration 1
+        L[2, n, a[1]] = -2.0 - rng.random()
+    od = oracle.Decoder(oracle.Code(edges=(N, M, q, ev, ec, eh)), oracle.GF(q), oracle.BP, 2, oracle.LITERAL)
+    ref = []
+    for b in range(B):
+        r, o, it = od.decode(L[b])
+        ref.append((r, o.copy(), it, [x.copy() for x in od.state()]))
+    for variant in (0, 1):
+        dec = nb.Decoder(code, nb.METHOD_BP, 2)
+        _force_generic(dec, variant)
+        dec.record_state(True)
+        out, conv, iters = dec.decode(L)
+        for b in range(B):
+            r, o, it, st = ref[b]
+            assert (conv[b], iters[b]) == (r, it) and np.array_equal(out[b], o), (variant, b)
+            for k, (a, rf) in enumerate(zip(dec.read_state(b), st)):
+                assert np.all(np.isfinite(a)), (variant, b)
+                if k == 1 and r == 1 and it >= 2:
+                    continue  # converged frame: v2c of the converging iteration vs the reference's previous one (include/nbldpc.h)
+                assert np.max(np.abs(a - rf)) <= LLR_TOL * max(1.0, np.max(np.abs(rf))), (variant, b)
+        dec.close()
+    assert [x[0] for x in ref] != [1, 1, 1]  # at least one frame ran both check-node passes
+
+
 @pytest.mark.parametrize("method,codename,kw", [
     (2, "divsalar.UNBLDPC.128.64.GF.256", dict(ems_nm=16, ems_nc=3)),
     (2, "divsalar.UNBLDPC.128.64.GF.16", dict(ems_nm=8, ems_nc=2)),
     (4, "BDS.576.288.GF.64", dict(tems_nr=2, tems_nc=3)),
     (1, "divsalar.UNBLDPC.128.64.GF.16", dict()),
+    (1, "divsalar.CNBLDPC.512.256.GF.256", dict()),
 ])
 def test_non_finite_inputs_terminate(method, codename, kw):
     """Garbage in (NaN, +-inf, 1e300) must not hang or fault any kernel: every data-dependent loop is bounded.  Outputs are
