@@ -62,9 +62,7 @@ int nblh_simulate(const char *profile, int device, double *rows, int max_rows)
 	if (!link.Initial(profile, devs)) return -1;
 	int n = 0;
 	while (link.sim.NextSNR()) {
-		link.BeginSNR();
-		while (link.sim.SimulateThisSNR())
-			if (!link.Cycle()) return -2;
+		if (!link.RunPoint(false)) return -2;
 		if (n < max_rows) {
 			double *r = rows + 9 * n;
 			r[0] = link.sim.EbN0; r[1] = link.sim.errFrame; r[2] = link.sim.errSym; r[3] = link.sim.errBit; r[4] = link.sim.U_errFrame;

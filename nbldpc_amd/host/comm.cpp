@@ -5,6 +5,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <vector>
 
 // seed + lane for the three generators, PN register pre-advanced lane steps (Comm.cpp:58-74, :160-173)
 void CComm::ResetSources(CSimulation &sim, int lane)
@@ -13,7 +14,7 @@ void CComm::ResetSources(CSimulation &sim, int lane)
 	if (lane) { Rand.IX += lane; Rand.IY += lane; Rand.IZ += lane; }
 	static const int init[11] = {1, 0, 1, 0, 0, 0, 1, 1, 0, 0, 1};
 	memcpy(regPN, init, sizeof init);
-	for (int k = 0; k < lane; k++) GenPN();
+	SkipPN(lane);
 }
 
 bool CComm::Initial(CSimulation &sim, int lane, CNBLDPC *shared)
@@ -134,13 +135,52 @@ int CComm::GenPN()
 	return regPN[10];
 }
 
+// The register update is a linear map of an 11-bit state, so "clock it n times" is a table walk: the map is squared
+// repeatedly (2048-entry tables) and the tables of the set bits of n are applied.  Same register contents as n calls of
+// GenPN(); the reference clocks one by one (Comm.cpp:201), which is O(parallel) per message bit.
+namespace {
+struct PnTables {
+	std::vector<std::vector<unsigned short>> pow2; // pow2[k][state] = state after 2^k clocks
+	PnTables()
+	{
+		std::vector<unsigned short> t(2048);
+		for (int s = 0; s < 2048; s++) { // bit i of s = regPN[i]
+			const int fb = ((s >> 9) ^ (s >> 2)) & 1; // the feedback is taken after the shift (Comm.cpp:246-250)
+			t[s] = (unsigned short)(((s << 1) & 2047) | fb);
+		}
+		pow2.push_back(t);
+		for (int k = 1; k < 31; k++) {
+			std::vector<unsigned short> n(2048);
+			for (int s = 0; s < 2048; s++) n[s] = pow2[k - 1][pow2[k - 1][s]];
+			pow2.push_back(n);
+		}
+	}
+};
+const PnTables &pn_tables()
+{
+	static const PnTables t;
+	return t;
+}
+} // namespace
+
+void CComm::SkipPN(int n)
+{
+	if (n <= 0) return;
+	const PnTables &t = pn_tables();
+	int s = 0;
+	for (int i = 0; i < 11; i++) s |= regPN[i] << i;
+	for (int k = 0; k < 31; k++)
+		if ((n >> k) & 1) s = t.pow2[k][s];
+	for (int i = 0; i < 11; i++) regPN[i] = (s >> i) & 1;
+}
+
 // every lane draws from the SAME PN sequence, interleaved: lane i uses outputs i, i+P, i+2P, .. (Comm.cpp:199-202)
 int CComm::GenerateMessage()
 {
 	const int nb = MSG_BIT_LEN - crcLen;
 	for (int b = 0; b < nb; b++) {
 		if (randomMsg) {
-			for (int k = 0; k < parallel_num - 1; k++) GenPN();
+			SkipPN(parallel_num - 1);
 			TX_MSG_BIT_beforeCRC[b] = GenPN();
 		} else {
 			TX_MSG_BIT_beforeCRC[b] = 0;
@@ -286,18 +326,44 @@ int CComm::TakeDecoded(const int *decoded, bool converged) // Comm.cpp:421-443
 int CComm::Err(CSimulation &sim) // Comm.cpp:446-503
 {
 	double errSym = 0, errBit = 0;
-	for (int s = 0; s < MSG_SYM_LEN; s++) errSym += (TX_MSG_SYM[s] != RX_MSG_SYM[s]);
-	for (int b = 0; b < MSG_BIT_LEN; b++) errBit += (TX_MSG_BIT[b] != RX_MSG_BIT[b]);
-	const int crc_ok = CrcCheck(RX_MSG_BIT.data(), MSG_BIT_LEN, crcLen, 1);
+	int crc_ok = 0;
+	ErrCount(-1, errSym, errBit, crc_ok);
+	ErrAccumulate(sim, errSym, errBit, crc_ok);
+	ErrRates(sim);
+	return 0;
+}
+
+void CComm::HoldTx(int slot)
+{
+	HOLD_MSG_SYM[slot] = TX_MSG_SYM;
+	HOLD_MSG_BIT[slot] = TX_MSG_BIT;
+}
+
+// slot < 0: compare with the live TX buffers (serial driver), else with the message held for that cycle
+void CComm::ErrCount(int slot, double &errSym, double &errBit, int &crc_ok)
+{
+	const std::vector<int> &msg_sym = slot < 0 ? TX_MSG_SYM : HOLD_MSG_SYM[slot];
+	const std::vector<int> &msg_bit = slot < 0 ? TX_MSG_BIT : HOLD_MSG_BIT[slot];
+	errSym = errBit = 0;
+	for (int s = 0; s < MSG_SYM_LEN; s++) errSym += (msg_sym[s] != RX_MSG_SYM[s]);
+	for (int b = 0; b < MSG_BIT_LEN; b++) errBit += (msg_bit[b] != RX_MSG_BIT[b]);
+	crc_ok = CrcCheck(RX_MSG_BIT.data(), MSG_BIT_LEN, crcLen, 1);
+}
+
+void CComm::ErrAccumulate(CSimulation &sim, double errSym, double errBit, int crc_ok)
+{
 	sim.errSym += errSym;
 	sim.errBit += errBit;
 	sim.errFrame += (errSym != 0) ? 1 : 0;
 	if (crc_ok && errSym != 0) { sim.U_errSym += errSym; sim.U_errBit += errBit; sim.U_errFrame += 1; }
+}
+
+void CComm::ErrRates(CSimulation &sim) const
+{
 	sim.SER = sim.errSym / (sim.simCycle * MSG_SYM_LEN * sim.parallel);
 	sim.BER = sim.errBit / (sim.simCycle * MSG_BIT_LEN * sim.parallel);
 	sim.FER = sim.errFrame / (sim.simCycle * sim.parallel);
 	sim.U_SER = sim.U_errSym / (sim.simCycle * MSG_SYM_LEN * sim.parallel);
 	sim.U_BER = sim.U_errBit / (sim.simCycle * MSG_BIT_LEN * sim.parallel);
 	sim.U_FER = sim.U_errFrame / (sim.simCycle * sim.parallel);
-	return 0;
 }

@@ -45,8 +45,16 @@ public:
 	int Demodulate();
 	int TakeDecoded(const int *decoded_sym, bool converged);
 	int Err(CSimulation &sim);
+	// Err() in two halves for the pipelined driver: HoldTx keeps the transmitted message of this cycle while the next cycle's
+	// front-end already runs; ErrCount is lane-local (thread-safe); ErrAccumulate adds into the shared counters in lane order.
+	void HoldTx(int slot);
+	void ErrCount(int slot, double &errSym, double &errBit, int &crc_ok);
+	static void ErrAccumulate(CSimulation &sim, double errSym, double errBit, int crc_ok);
+	void ErrRates(CSimulation &sim) const;
+	std::vector<int> HOLD_MSG_SYM[2], HOLD_MSG_BIT[2];
 	std::string error;
 
 private:
 	void ResetSources(CSimulation &sim, int parallel_order);
+	void SkipPN(int n); // clock the PN register n times (table walk)
 };

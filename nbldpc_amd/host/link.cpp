@@ -3,7 +3,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <chrono>
 #include <thread>
+
+static double now_s()
+{
+	return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 bool CLink::Initial(const std::string &profile, int device) { return Initial(profile, std::vector<int>{device}); }
 
@@ -11,6 +17,7 @@ bool CLink::Initial(const std::string &profile, int device) { return Initial(pro
 // multi-GPU path is a static split of the batch with no exchange between devices; Err() still runs in lane order.
 bool CLink::Initial(const std::string &profile, const std::vector<int> &device_list)
 {
+	const double t0 = now_s();
 	if (sim.Initial(profile) != 0) { error = "cannot read profile " + profile; return false; }
 	devices = device_list.empty() ? std::vector<int>{0} : device_list;
 	if (!code.Initial(sim, devices[0])) { error = code.LastError(); return false; }
@@ -26,6 +33,11 @@ bool CLink::Initial(const std::string &profile, const std::vector<int> &device_l
 	}
 	const size_t per = (size_t)code.CodeLen * (code.GFq - 1);
 	if (const char *e = getenv("NBL_DEVICE_DEMOD")) device_demod = atoi(e) != 0;
+	if (const char *e = getenv("NBL_PIPELINE")) pipeline = atoi(e) != 0;
+	if (const char *e = getenv("NBL_HOST_THREADS")) host_threads = atoi(e);
+	else { host_threads = (int)std::thread::hardware_concurrency(); if (host_threads > 16) host_threads = 16; }
+	if (host_threads > sim.parallel) host_threads = sim.parallel;
+	if (host_threads < 1) host_threads = 1;
 	if (device_demod) {
 		std::vector<int> src;
 		lanes[0]->DemodSource(src);
@@ -34,12 +46,15 @@ bool CLink::Initial(const std::string &profile, const std::vector<int> &device_l
 		if (code.SetDemodulator(lanes[0]->modOrder, lanes[0]->MOD_SYM_LEN, cons.data(), src.data()) != 0) { error = code.LastError(); return false; }
 		for (auto &x : extra)
 			if (x->SetDemodulator(lanes[0]->modOrder, lanes[0]->MOD_SYM_LEN, cons.data(), src.data()) != 0) { error = x->LastError(); return false; }
-		rx_batch.assign((size_t)2 * lanes[0]->MOD_SYM_LEN * sim.parallel, 0.0);
 	}
-	L_batch.assign(device_demod ? 0 : per * sim.parallel, 0.0);
+	for (int slot = 0; slot < (pipeline ? 2 : 1); slot++) {
+		rx_batch[slot].assign(device_demod ? (size_t)2 * lanes[0]->MOD_SYM_LEN * sim.parallel : 0, 0.0);
+		L_batch[slot].assign(device_demod ? 0 : per * sim.parallel, 0.0);
+	}
 	out_batch.assign((size_t)code.CodeLen * sim.parallel, 0);
 	iters.assign(sim.parallel, 0);
 	conv.assign(sim.parallel, 0);
+	t_init = now_s() - t0;
 	return true;
 }
 
@@ -49,66 +64,131 @@ void CLink::BeginSNR()
 	for (int i = 0; i < sim.parallel; i++) lanes[i]->SetEbN0(sim, i);
 }
 
-bool CLink::Cycle()
+template <class F> static void over_lanes(int P, int T, F work)
 {
-	const int P = sim.parallel;
+	if (T <= 1) { work(0, P); return; }
+	std::vector<std::thread> th;
+	for (int t = 0; t < T; t++) th.emplace_back(work, (int)((long long)P * t / T), (int)((long long)P * (t + 1) / T));
+	for (auto &x : th) x.join();
+}
+
+// lanes own their RNG / PN / buffers, so their front-ends run in parallel exactly like the reference's parallel_for
+// (main.cpp:46); results do not depend on the thread count
+void CLink::FrontEnds(int slot)
+{
 	const size_t per = (size_t)code.CodeLen * (code.GFq - 1);
-	// lanes own their RNG / PN / buffers, so their front-ends run in parallel exactly like the reference's parallel_for
-	// (main.cpp:46); results do not depend on the thread count
-	auto work = [&](int lo, int hi) {
+	over_lanes(sim.parallel, host_threads, [&](int lo, int hi) {
 		for (int i = lo; i < hi; i++) {
 			if (device_demod) {
 				lanes[i]->FrontEndToChannel();
 				const int L = lanes[i]->MOD_SYM_LEN;
+				double *rx = &rx_batch[slot][(size_t)i * L * 2];
 				for (int s = 0; s < L; s++) {
-					rx_batch[((size_t)i * L + s) * 2] = lanes[i]->RX_MOD_SYM[s].Real;
-					rx_batch[((size_t)i * L + s) * 2 + 1] = lanes[i]->RX_MOD_SYM[s].Image;
+					rx[2 * s] = lanes[i]->RX_MOD_SYM[s].Real;
+					rx[2 * s + 1] = lanes[i]->RX_MOD_SYM[s].Image;
 				}
 			} else {
 				lanes[i]->FrontEnd();
-				memcpy(&L_batch[per * i], lanes[i]->RX_LLR_SYM.data(), sizeof(double) * per);
+				memcpy(&L_batch[slot][per * i], lanes[i]->RX_LLR_SYM.data(), sizeof(double) * per);
 			}
+			lanes[i]->HoldTx(slot);
 		}
-	};
-	int T = 1;
-	if (const char *e = getenv("NBL_HOST_THREADS")) T = atoi(e);
-	else { T = (int)std::thread::hardware_concurrency(); if (T > 16) T = 16; }
-	if (T > P) T = P;
-	if (T <= 1) work(0, P);
-	else {
-		std::vector<std::thread> th;
-		for (int t = 0; t < T; t++) th.emplace_back(work, (int)((long long)P * t / T), (int)((long long)P * (t + 1) / T));
-		for (auto &x : th) x.join();
-	}
+	});
+}
+
+bool CLink::Decode(int slot)
+{
+	const int P = sim.parallel;
+	const size_t per = (size_t)code.CodeLen * (code.GFq - 1);
 	const int G = (int)devices.size();
 	const size_t rxper = device_demod ? (size_t)2 * lanes[0]->MOD_SYM_LEN : 0;
 	const double sigma = lanes[0]->sigma_n;
-	if (G == 1) {
-		const int rc1 = device_demod ? code.DecodingBatchSamples(rx_batch.data(), sigma, P, out_batch.data(), conv.data(), iters.data())
-		                             : code.DecodingBatch(L_batch.data(), P, out_batch.data(), conv.data(), iters.data());
-		if (rc1 != 0) { error = code.LastError(); return false; }
-	} else {
+	std::vector<int> rc(G, 0);
+	auto shard = [&](int gidx) {
+		const int lo = (int)((long long)P * gidx / G), hi = (int)((long long)P * (gidx + 1) / G);
+		CNBLDPC &dec = gidx == 0 ? code : *extra[gidx - 1];
+		if (hi > lo)
+			rc[gidx] = device_demod
+			    ? dec.DecodingBatchSamples(&rx_batch[slot][rxper * lo], sigma, hi - lo, &out_batch[(size_t)code.CodeLen * lo], &conv[lo], &iters[lo])
+			    : dec.DecodingBatch(&L_batch[slot][per * lo], hi - lo, &out_batch[(size_t)code.CodeLen * lo], &conv[lo], &iters[lo]);
+	};
+	if (G == 1) shard(0);
+	else {
 		std::vector<std::thread> th;
-		std::vector<int> rc(G, 0);
-		for (int gidx = 0; gidx < G; gidx++) {
-			th.emplace_back([&, gidx]() {
-				const int lo = (int)((long long)P * gidx / G), hi = (int)((long long)P * (gidx + 1) / G);
-				CNBLDPC &dec = gidx == 0 ? code : *extra[gidx - 1];
-				if (hi > lo)
-					rc[gidx] = device_demod
-					    ? dec.DecodingBatchSamples(&rx_batch[rxper * lo], sigma, hi - lo, &out_batch[(size_t)code.CodeLen * lo], &conv[lo], &iters[lo])
-					    : dec.DecodingBatch(&L_batch[per * lo], hi - lo, &out_batch[(size_t)code.CodeLen * lo], &conv[lo], &iters[lo]);
-			});
-		}
+		for (int gidx = 0; gidx < G; gidx++) th.emplace_back(shard, gidx);
 		for (auto &x : th) x.join();
-		for (int gidx = 0; gidx < G; gidx++)
-			if (rc[gidx] != 0) { error = (gidx == 0 ? code : *extra[gidx - 1]).LastError(); return false; }
 	}
-	for (int i = 0; i < P; i++) {
-		lanes[i]->TakeDecoded(&out_batch[(size_t)code.CodeLen * i], conv[i] != 0);
-		lanes[i]->Err(sim); // serial, lane order: same accumulation order as main.cpp:48-51
-	}
+	for (int gidx = 0; gidx < G; gidx++)
+		if (rc[gidx] != 0) { error = (gidx == 0 ? code : *extra[gidx - 1]).LastError(); return false; }
+	return true;
+}
+
+// The counters are integer-valued doubles, so adding the per-lane counts in lane order afterwards gives exactly what the
+// reference's serial Err() loop gives (main.cpp:48-51); the rates are its last lane's expressions on the final totals.
+void CLink::CountErrors(int slot)
+{
+	const int P = sim.parallel;
+	std::vector<double> es(P), eb(P);
+	std::vector<int> ok(P);
+	over_lanes(P, host_threads, [&](int lo, int hi) {
+		for (int i = lo; i < hi; i++) {
+			lanes[i]->TakeDecoded(&out_batch[(size_t)code.CodeLen * i], conv[i] != 0);
+			lanes[i]->ErrCount(slot, es[i], eb[i], ok[i]);
+		}
+	});
+	for (int i = 0; i < P; i++) CComm::ErrAccumulate(sim, es[i], eb[i], ok[i]);
+	lanes[P - 1]->ErrRates(sim);
 	sim.decoded_frames += P;
+	n_frames += P;
+}
+
+bool CLink::Cycle()
+{
+	const double t0 = now_s();
+	FrontEnds(0);
+	const double t1 = now_s();
+	if (!Decode(0)) return false;
+	const double t2 = now_s();
+	CountErrors(0);
+	t_front += t1 - t0;
+	t_decode += t2 - t1;
+	t_err += now_s() - t2;
+	return true;
+}
+
+// Pipelined driver: while the GPUs decode cycle k the host threads already run the link chain of cycle k+1 into the other
+// buffer.  Every cycle sees exactly the frames it would see in the serial order (lanes keep their own generators), and the
+// stop rule is evaluated after each cycle's error count as before; the one speculative front-end at the end of an Eb/N0 point
+// is discarded, and SetEbN0 re-seeds every lane for the next point (Comm.cpp:160-173), so the results are identical.
+bool CLink::RunPoint(bool verbose)
+{
+	BeginSNR();
+	if (!pipeline) {
+		while (sim.SimulateThisSNR()) {
+			if (!Cycle()) return false;
+			if (verbose) sim.Show(Screen_Sim_Data);
+		}
+		return true;
+	}
+	int slot = 0;
+	bool primed = false;
+	while (sim.SimulateThisSNR()) {
+		double t0 = now_s();
+		if (!primed) { FrontEnds(slot); primed = true; t_front += now_s() - t0; t0 = now_s(); }
+		bool ok = true;
+		std::thread dec([&]() { ok = Decode(slot); });
+		FrontEnds(slot ^ 1); // cycle k+1 (speculative if the stop rule ends this point)
+		const double t1 = now_s();
+		dec.join();
+		const double t2 = now_s();
+		if (!ok) return false;
+		CountErrors(slot);
+		t_front += t1 - t0;   // host time that ran under the decode
+		t_decode += t2 - t1;  // decode time NOT hidden by the front-end
+		t_err += now_s() - t2;
+		slot ^= 1;
+		if (verbose) sim.Show(Screen_Sim_Data);
+	}
 	return true;
 }
 
@@ -116,11 +196,7 @@ void CLink::RunAll(bool verbose)
 {
 	if (verbose) { sim.Show(Screen_Logo); sim.Show(Screen_Conf); sim.Show(Screen_Head); }
 	while (sim.NextSNR()) {
-		BeginSNR();
-		while (sim.SimulateThisSNR()) {
-			if (!Cycle()) { std::cerr << error << std::endl; return; }
-			if (verbose) sim.Show(Screen_Sim_Data);
-		}
+		if (!RunPoint(verbose)) { std::cerr << error << std::endl; return; }
 		if (verbose) sim.Show(Screen_Sim_End_Data);
 	}
 }

@@ -12,16 +12,24 @@ public:
 	std::vector<std::unique_ptr<CNBLDPC>> extra; // one more decoder per additional GPU (lanes sharded, no collective)
 	std::vector<int> devices;
 	std::vector<std::unique_ptr<CComm>> lanes;
-	std::vector<double> L_batch;       // [parallel][N][q-1]
+	std::vector<double> L_batch[2];    // [parallel][N][q-1], one buffer per cycle in flight
 	bool device_demod = false;         // NBL_DEVICE_DEMOD=1: ship received samples, demodulate on the GPU
-	std::vector<double> rx_batch;      // [parallel][MOD_SYM_LEN][2]
+	std::vector<double> rx_batch[2];   // [parallel][MOD_SYM_LEN][2]
+	bool pipeline = true;              // NBL_PIPELINE=0: strictly serial cycles
+	int host_threads = 1;
 	std::vector<int> out_batch, iters;
 	std::vector<uint8_t> conv;
 	std::string error;
+	double t_init = 0, t_front = 0, t_decode = 0, t_err = 0; // wall seconds per phase, summed over all cycles
+	long long n_frames = 0;
 
 	bool Initial(const std::string &profile, int device = 0);
 	bool Initial(const std::string &profile, const std::vector<int> &device_list);
 	void BeginSNR();                   // ClearSimuCount + SetEbN0 on every lane
 	bool Cycle();                      // front-ends, one batched decode, Err per lane in lane order
+	void FrontEnds(int slot);          // every lane's link chain for one cycle, into buffer `slot` (threaded over lanes)
+	bool Decode(int slot);             // one batched decode per GPU of buffer `slot`
+	void CountErrors(int slot);        // unpack + compare per lane (threaded), counters added in lane order
+	bool RunPoint(bool verbose);       // one Eb/N0 point: BeginSNR, then cycles until the stop rule ends it (pipelined by default)
 	void RunAll(bool verbose);
 };

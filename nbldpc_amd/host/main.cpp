@@ -28,5 +28,8 @@ int main(int argc, char **argv)
 	}
 	link.RunAll(true);
 	std::cout << std::endl;
+	const double tot = link.t_front + link.t_decode + link.t_err;
+	std::cerr << "[nbldpc_sim] " << link.n_frames << " frames: set-up " << link.t_init << " s, front-end " << link.t_front << " s, decode "
+	          << link.t_decode << " s, error count " << link.t_err << " s  -> " << (tot > 0 ? link.n_frames / tot : 0.0) << " frames/s" << std::endl;
 	return 0;
 }
