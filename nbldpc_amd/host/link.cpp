@@ -35,7 +35,11 @@ bool CLink::Initial(const std::string &profile, const std::vector<int> &device_l
 	if (const char *e = getenv("NBL_DEVICE_DEMOD")) device_demod = atoi(e) != 0;
 	if (const char *e = getenv("NBL_PIPELINE")) pipeline = atoi(e) != 0;
 	if (const char *e = getenv("NBL_HOST_THREADS")) host_threads = atoi(e);
-	else { host_threads = (int)std::thread::hardware_concurrency(); if (host_threads > 16) host_threads = 16; }
+	else { // 16 threads keep one GPU fed; more GPUs decode more lanes per cycle
+		host_threads = (int)std::thread::hardware_concurrency();
+		const int cap = 16 * (int)devices.size();
+		if (host_threads > cap) host_threads = cap;
+	}
 	if (host_threads > sim.parallel) host_threads = sim.parallel;
 	if (host_threads < 1) host_threads = 1;
 	if (device_demod) {
