@@ -88,16 +88,21 @@ static void free_workspace(nbl_decoder *d)
 	d->ws_bytes = 0;
 }
 
-// EMS on a (2,4)-regular GF(256) code with nc >= 3 and nm in {8,16,32}: the whole iteration is one fused launch
+// Shapes whose whole iteration is ONE launch (variable-node pass recomputed inside the check-node kernel, c2v double-buffered):
+// (2,4)-regular codes, EMS over GF(256) with nm in {8,16,32}, T-EMS over GF(64).
 static bool fused_shape(const nbl_decoder *d)
 {
-	return d->prm.method == NBL_METHOD_EMS && d->all_dv2 && nbl_ems256_applicable(d->g, d->all_dc4, d->prm.ems_nm, d->prm.ems_nc);
+	if (!d->all_dv2) return false;
+	if (d->prm.method == NBL_METHOD_EMS) return nbl_ems256_applicable(d->g, d->all_dc4, d->prm.ems_nm, d->prm.ems_nc);
+	if (d->prm.method == NBL_METHOD_TEMS) return nbl_tems64_applicable(d->g, d->all_dc4, d->prm.tems_nr, d->prm.tems_nc);
+	return false;
 }
 
 static nbl_status ensure_workspace(nbl_decoder *d, int B)
 {
 	// v2c only exists in HBM when something reads it: the unfused path, or state read-back
-	const bool want_v2c = !fused_shape(d) || d->record_state || d->force_generic != 0;
+	// (damped methods always keep it: the damping reads the previous iteration's v2c)
+	const bool want_v2c = d->prm.method != NBL_METHOD_EMS || !fused_shape(d) || d->record_state || d->force_generic != 0;
 	if (B <= d->cap && (!d->record_state || d->w.post) && (!want_v2c || d->w.v2c)) return NBL_OK;
 	int cap = B > d->cap ? B : d->cap;
 	free_workspace(d);
@@ -309,7 +314,7 @@ static nbl_status launch_cn(nbl_decoder *d, const NblRun &r, hipStream_t st)
 		else HIP_TRY(d, nbl_launch_cn_ems(d->g, d->w, r, st));
 		break;
 	case NBL_METHOD_TEMS:
-		if (d->force_generic != 1 && nbl_tems64_applicable(d->g, d->all_dc4, r.nr, r.nc)) HIP_TRY(d, nbl_launch_cn_tems64(d->g, d->w, r, st));
+		if (d->force_generic != 1 && nbl_tems64_applicable(d->g, d->all_dc4, r.nr, r.nc)) HIP_TRY(d, nbl_launch_cn_tems64(d->g, d->w, r, false, st));
 		else HIP_TRY(d, nbl_launch_cn_tems(d->g, d->w, r, st));
 		break;
 	case NBL_METHOD_BP:
@@ -352,12 +357,13 @@ static nbl_status run_iterations(nbl_decoder *d, const double *d_Lin, int B, hip
 	for (int it = 1; it <= p.max_iter; it++) {
 		r.iter = it;
 		if (fused) {
-			// one launch = variable-node pass + EMS check-node pass; c2v ping-pongs between the two buffers
+			// one launch = variable-node pass + check-node pass; c2v ping-pongs between the two buffers
 			NblWork wf = d->w;
 			wf.c2v_prev = (it & 1) ? bufA : bufB;
 			wf.c2v = (it & 1) ? bufB : bufA;
 			wf.store_v2c = d->record_state ? 1 : 0;
-			HIP_TRY(d, nbl_launch_cn_ems256(d->g, wf, r, true, st));
+			if (p.method == NBL_METHOD_EMS) HIP_TRY(d, nbl_launch_cn_ems256(d->g, wf, r, true, st));
+			else HIP_TRY(d, nbl_launch_cn_tems64(d->g, wf, r, true, st));
 			HIP_TRY(d, mark(2));
 			d->launches[2]++;
 			d->last_c2v = wf.c2v;

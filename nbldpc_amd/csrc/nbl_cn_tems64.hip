@@ -36,6 +36,7 @@ __device__ __forceinline__ double pick(const double (&u)[DC], int k)
 	return k == 0 ? u[0] : k == 1 ? u[1] : k == 2 ? u[2] : u[3];
 }
 
+template <bool FUSED>
 __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	__shared__ double dU[DC][Q];                            // delta-domain trellis (:1814-1834)
@@ -48,15 +49,49 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m];
 	const int nr = r.nr, nc = r.nc;
-	const double *V = w.v2c + (size_t)b * g.E * Q;
+	double *V = w.v2c + (size_t)b * g.E * Q;
 	double *C = w.c2v + ((size_t)b * g.E + c0) * Q;
+
+	// ---- 0. FUSED: the variable-node pass of this iteration for the four incoming edges (NBLDPC.cpp:977-992, :1029-1052) ----
+	// post = (L_ch + c2v_0) + c2v_1 of the edge's variable (dv = 2), hard decision by the check that holds the variable's
+	// first edge, v2c = post - c2v of this edge, damped 1/4 : 3/4 against the previous v2c when its hard decision moves.
+	double vin[DC];
+	if (FUSED) {
+		const double *Cp = w.c2v_prev + (size_t)b * g.E * Q;
+		double l[DC], ca[DC], cb[DC], ov[DC];
+		int nvar[DC], eidx[DC];
+		bool ownA[DC];
+#pragma unroll
+		for (int d = 0; d < DC; d++) { // every load first
+			const int n = g.c_var[c0 + d], e = g.c_epos[c0 + d], e0 = g.voff[n];
+			l[d] = w.Lch[((size_t)b * g.N + n) * Q + lane];
+			ca[d] = Cp[(size_t)g.v_cpos[e0] * Q + lane];
+			cb[d] = Cp[(size_t)g.v_cpos[e0 + 1] * Q + lane];
+			ov[d] = V[(size_t)e * Q + lane];
+			nvar[d] = n; eidx[d] = e; ownA[d] = (e == e0);
+		}
+#pragma unroll
+		for (int d = 0; d < DC; d++) {
+			const double post[1] = {(l[d] + ca[d]) + cb[d]};
+			if (ownA[d]) {
+				const int dec = wave_decide<1>(post, lane, Q);
+				if (lane == 0) w.dec[(size_t)b * g.N + nvar[d]] = dec;
+				if (w.post) w.post[((size_t)b * g.N + nvar[d]) * Q + lane] = post[0];
+			}
+			double nv[1] = {post[0] - (ownA[d] ? ca[d] : cb[d])};
+			const double old[1] = {ov[d]};
+			if (wave_decide<1>(old, lane, Q) != wave_decide<1>(nv, lane, Q))
+				nv[0] = __dadd_rn(__dmul_rn(r.damp_old, old[0]), __dmul_rn(r.damp_new, nv[0]));
+			vin[d] = lane == 0 ? 0.0 : nv[0];
+			V[(size_t)eidx[d] * Q + lane] = vin[d];
+		}
+	}
 
 	// ---- 1. beta, syndrome, dU -------------------------------------------------------------------------------------------
 	int beta[DC], hmul[DC], syn = 0;
 #pragma unroll
 	for (int d = 0; d < DC; d++) {
-		const double *Vd = V + (size_t)g.c_epos[c0 + d] * Q;
-		const double v = lane > 0 ? Vd[lane] : 0.0;
+		const double v = FUSED ? vin[d] : (lane > 0 ? V[(size_t)g.c_epos[c0 + d] * Q + lane] : 0.0);
 		// most reliable symbol: strict '>' over ascending symbols from a running maximum of 0 (:1798-1807) = the lowest symbol
 		// that holds the maximum of {0, v[1..]}; symbol 0 (value 0) when nothing is positive
 		const double mx = wave_fmax(v);
@@ -186,9 +221,10 @@ bool nbl_tems64_applicable(const NblGraphDev &g, bool all_dc4, int nr, int nc)
 	return g.q == 64 && all_dc4 && nc >= 1 && nc <= 3 && nr >= 1 && nr <= 4;
 }
 
-hipError_t nbl_launch_cn_tems64(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
+hipError_t nbl_launch_cn_tems64(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 {
 	dim3 grid((unsigned)((long long)r.B * g.M)), block(64);
-	cn_tems_q64_dc4_kernel<<<grid, block, 0, st>>>(g, w, r);
+	if (fused) cn_tems_q64_dc4_kernel<true><<<grid, block, 0, st>>>(g, w, r);
+	else cn_tems_q64_dc4_kernel<false><<<grid, block, 0, st>>>(g, w, r);
 	return hipGetLastError();
 }

@@ -266,7 +266,7 @@ def test_tems_gf64_every_shape_ties_and_erasures_vs_oracle(oracle, nr, nc):
                 r, o, it = od.decode(L[b])
                 ref.append((r, o.copy(), it, [x.copy() for x in od.state()]))
             refs.append(ref)
-        for variant in (0, 1):
+        for variant in (0, 1, 2):  # fused iteration, general kernels, specialised check node behind the separate VN pass
             dec = nb.Decoder(code, nb.METHOD_TEMS, 3, **kw)
             _force_generic(dec, variant)
             dec.record_state(True)
