@@ -116,7 +116,8 @@ nbl_status nbl_decode_batch_samples(nbl_decoder *dec, const double *rx, double s
  * post [N][q-1], v2c [E][q-1], c2v [E][q-1], edges in variable-major order.  For parity tests.
  * post and c2v are the reference's members at return.  v2c differs for a codeword that CONVERGED at iteration k >= 2: the
  * variable-node pass writes the messages of iteration k before the syndrome is known, the reference returns with those of
- * iteration k-1 (NBLDPC.cpp:693-715 precedes :718-744); they are never used afterwards. */
+ * iteration k-1 (NBLDPC.cpp:693-715 precedes :718-744); they are never used afterwards.  In fixed-iteration mode (timing)
+ * the message buffers of a converged codeword keep being updated; only its outputs are frozen. */
 nbl_status nbl_read_state(nbl_decoder *dec, int32_t b, double *post, double *v2c, double *c2v);
 
 /* Keep L_post of the last variable-node pass so nbl_read_state can return it (costs N q-vectors of

@@ -31,6 +31,7 @@ struct nbl_decoder {
 	bool all_dv2 = false;       // every variable has degree 2
 	double *c2v_alt = nullptr;  // second c2v buffer of the fused EMS iteration (flooding schedule -> double buffer)
 	const double *last_c2v = nullptr;
+	bool last_fused = false;    // the last decode ran fused iterations (nbl_read_state picks the c2v buffer per codeword)
 	// device-side demodulator (nbl_set_demodulator)
 	int dm_order = 0, dm_L = 0;
 	double *d_cons = nullptr;
@@ -89,12 +90,13 @@ static void free_workspace(nbl_decoder *d)
 }
 
 // Shapes whose whole iteration is ONE launch (variable-node pass recomputed inside the check-node kernel, c2v double-buffered):
-// (2,4)-regular codes, EMS over GF(256) with nm in {8,16,32}, T-EMS over GF(64).
+// (2,4)-regular codes, EMS over GF(256) with nm in {8,16,32}, T-EMS over GF(64), log-QSPA over GF(256).
 static bool fused_shape(const nbl_decoder *d)
 {
 	if (!d->all_dv2) return false;
 	if (d->prm.method == NBL_METHOD_EMS) return nbl_ems256_applicable(d->g, d->all_dc4, d->prm.ems_nm, d->prm.ems_nc);
 	if (d->prm.method == NBL_METHOD_TEMS) return nbl_tems64_applicable(d->g, d->all_dc4, d->prm.tems_nr, d->prm.tems_nc);
+	if (d->prm.method == NBL_METHOD_BP) return nbl_bp256_applicable(d->g, d->all_dc4);
 	return false;
 }
 
@@ -318,7 +320,7 @@ static nbl_status launch_cn(nbl_decoder *d, const NblRun &r, hipStream_t st)
 		else HIP_TRY(d, nbl_launch_cn_tems(d->g, d->w, r, st));
 		break;
 	case NBL_METHOD_BP:
-		if (d->force_generic != 1 && nbl_bp256_applicable(d->g, d->all_dc4)) HIP_TRY(d, nbl_launch_cn_bp256(d->g, d->w, r, st));
+		if (d->force_generic != 1 && nbl_bp256_applicable(d->g, d->all_dc4)) HIP_TRY(d, nbl_launch_cn_bp256(d->g, d->w, r, false, st));
 		else HIP_TRY(d, nbl_launch_cn_bp(d->g, d->w, r, st));
 		break;
 	default: d->err = "check-node kernel for this method is not built yet"; return NBL_ERR_UNSUPPORTED;
@@ -354,6 +356,7 @@ static nbl_status run_iterations(nbl_decoder *d, const double *d_Lin, int B, hip
 	const bool fused = fused_shape(d) && d->force_generic == 0 && d->c2v_alt;
 	double *const bufA = d->w.c2v, *const bufB = d->c2v_alt;
 	d->last_c2v = bufA;
+	d->last_fused = fused;
 	for (int it = 1; it <= p.max_iter; it++) {
 		r.iter = it;
 		if (fused) {
@@ -363,7 +366,8 @@ static nbl_status run_iterations(nbl_decoder *d, const double *d_Lin, int B, hip
 			wf.c2v = (it & 1) ? bufB : bufA;
 			wf.store_v2c = d->record_state ? 1 : 0;
 			if (p.method == NBL_METHOD_EMS) HIP_TRY(d, nbl_launch_cn_ems256(d->g, wf, r, true, st));
-			else HIP_TRY(d, nbl_launch_cn_tems64(d->g, wf, r, true, st));
+			else if (p.method == NBL_METHOD_TEMS) HIP_TRY(d, nbl_launch_cn_tems64(d->g, wf, r, true, st));
+			else HIP_TRY(d, nbl_launch_cn_bp256(d->g, wf, r, true, st));
 			HIP_TRY(d, mark(2));
 			d->launches[2]++;
 			d->last_c2v = wf.c2v;
@@ -535,7 +539,19 @@ extern "C" nbl_status nbl_read_state(nbl_decoder *d, int32_t b, double *post, do
 		if (!d->w.v2c) { d->err = "v2c is not kept in HBM on the fused path unless state recording is on (nbl_set_record_state)"; rc = NBL_ERR_ARG; }
 		else rc = grab(d->w.v2c + (size_t)b * E * q, nullptr, E, v2c);
 	}
-	if (!rc && c2v) rc = grab((d->last_c2v ? d->last_c2v : d->w.c2v) + (size_t)b * E * q, d->d_e2c_map, E, c2v);
+	if (!rc && c2v) {
+		const double *src = d->last_c2v ? d->last_c2v : d->w.c2v;
+		if (d->last_fused && d->c2v_alt && !d->prm.fixed_iters) {
+			// fused iterations: a codeword that converged at iteration k has c2v(k) in one buffer (computed before its syndrome was
+			// known) and c2v(k-1), what the reference returns with, intact in the other; iteration i writes bufB when i is odd
+			int it = 0;
+			uint8_t done = 0;
+			HIP_TRY(d, hipMemcpy(&it, d->w.iters + b, sizeof it, hipMemcpyDeviceToHost));
+			HIP_TRY(d, hipMemcpy(&done, d->w.done + b, 1, hipMemcpyDeviceToHost));
+			if (done) src = ((it - 1) & 1) ? d->c2v_alt : d->w.c2v; // buffer written by iteration it-1 (it = 1: the zeroed bufA)
+		}
+		rc = grab(src + (size_t)b * E * q, d->d_e2c_map, E, c2v);
+	}
 	(void)hipFree(tmp);
 	return rc;
 }

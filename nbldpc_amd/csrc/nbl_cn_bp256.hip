@@ -162,6 +162,7 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 	__syncthreads(); // operands are rewritten by the next convolution
 }
 
+template <bool FUSED>
 __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	__shared__ __attribute__((aligned(16))) double smem[4 * Q]; // 8 KB: four permutation buffers, then the operands
@@ -171,19 +172,58 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m];
 
-	const double *V = w.v2c + (size_t)b * g.E * Q;
+	double *V = w.v2c + (size_t)b * g.E * Q;
 	double *C = w.c2v + ((size_t)b * g.E + c0) * Q;
 
 	// inputs into the check domain: p_d[h_d a] = v2c_d[a], symbol 0 = LLR 0 (the A1 == 0 branch of LLR_BoxPlus, :1623-1632)
 	GfMul<Q> mh[4];
 #pragma unroll
 	for (int d = 0; d < 4; d++) {
-		const double *Vd = V + (size_t)g.c_epos[c0 + d] * Q;
+		double *Vd = V + (size_t)g.c_epos[c0 + d] * Q;
 		mh[d].init(g.c_h[c0 + d], g.poly, lane);
+		if (!FUSED) {
 #pragma unroll
-		for (int i = 0; i < 4; i++) {
-			const int a = lane + 64 * i;
-			smem[d * Q + mh[d].at_slot(i)] = (a == 0) ? 0.0 : Vd[a];
+			for (int i = 0; i < 4; i++) {
+				const int a = lane + 64 * i;
+				smem[d * Q + mh[d].at_slot(i)] = (a == 0) ? 0.0 : Vd[a];
+			}
+		} else {
+			// FUSED: the variable-node pass of this iteration for this edge (NBLDPC.cpp:676-691, :718-744): post = (L_ch + c2v_0)
+			// + c2v_1 of the edge's variable (dv = 2), hard decision by the check that holds the variable's first edge,
+			// v2c = post - c2v of this edge, damped 1/2 : 1/2 against the previous v2c when its hard decision moves.
+			const double *Cp = w.c2v_prev + (size_t)b * g.E * Q;
+			const int n = g.c_var[c0 + d], e = g.c_epos[c0 + d], e0 = g.voff[n];
+			const double *pl = w.Lch + ((size_t)b * g.N + n) * Q;
+			const double *pa = Cp + (size_t)g.v_cpos[e0] * Q, *pb = Cp + (size_t)g.v_cpos[e0 + 1] * Q;
+			const bool ownA = (e == e0);
+			double post[4], nv[4], ov[4];
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const int a = lane + 64 * i;
+				const double ca = pa[a], cb = pb[a];
+				post[i] = (pl[a] + ca) + cb;
+				nv[i] = post[i] - (ownA ? ca : cb);
+				ov[i] = Vd[a];
+			}
+			if (ownA) {
+				const int dec = wave_decide<4>(post, lane, Q);
+				if (lane == 0) w.dec[(size_t)b * g.N + n] = dec;
+				if (w.post) {
+#pragma unroll
+					for (int i = 0; i < 4; i++) w.post[((size_t)b * g.N + n) * Q + lane + 64 * i] = post[i];
+				}
+			}
+			if (wave_decide<4>(ov, lane, Q) != wave_decide<4>(nv, lane, Q)) {
+#pragma unroll
+				for (int i = 0; i < 4; i++) nv[i] = __dadd_rn(__dmul_rn(r.damp_old, ov[i]), __dmul_rn(r.damp_new, nv[i]));
+			}
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const int a = lane + 64 * i;
+				const double x = (a == 0) ? 0.0 : nv[i];
+				V[(size_t)e * Q + a] = x;
+				smem[d * Q + mh[d].at_slot(i)] = x;
+			}
 		}
 	}
 	__syncthreads();
@@ -244,9 +284,10 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 
 bool nbl_bp256_applicable(const NblGraphDev &g, bool all_dc4) { return g.q == 256 && all_dc4; }
 
-hipError_t nbl_launch_cn_bp256(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
+hipError_t nbl_launch_cn_bp256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 {
 	dim3 grid((unsigned)((long long)r.B * g.M)), block(64);
-	cn_bp_q256_dc4_kernel<<<grid, block, 0, st>>>(g, w, r);
+	if (fused) cn_bp_q256_dc4_kernel<true><<<grid, block, 0, st>>>(g, w, r);
+	else cn_bp_q256_dc4_kernel<false><<<grid, block, 0, st>>>(g, w, r);
 	return hipGetLastError();
 }

@@ -28,4 +28,4 @@ hipError_t nbl_launch_cn_tems64(const NblGraphDev &g, const NblWork &w, const Nb
 
 // log-QSPA check node for GF(256), check degree 4 (nbl_cn_bp256.hip)
 bool nbl_bp256_applicable(const NblGraphDev &g, bool all_dc4);
-hipError_t nbl_launch_cn_bp256(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);
+hipError_t nbl_launch_cn_bp256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st);
