@@ -11,7 +11,7 @@ import numpy as np
 from . import datafiles
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnbldpc_hip.so")
+LIB_PATH = os.environ.get("NBL_HIP_LIB") or os.path.join(_HERE, "csrc", "libnbldpc_hip.so")  # NBL_HIP_LIB: A/B builds
 
 METHOD_BP, METHOD_EMS, METHOD_TEMS = 1, 2, 4
 

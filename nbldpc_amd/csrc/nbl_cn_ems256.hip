@@ -317,10 +317,10 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		double loc = dmax(dmax(v[j][0], v[j][1]), dmax(v[j][2], v[j][3]));
 		mtop[j] = wave_max_f64(loc);
 		lmin[j] = wave_min_f64(loc); // 64 distinct entries are >= lmin, so the nm-th best (nm <= 64) is too
-		int besta = -1;
+		uint64_t eqm[4];
 #pragma unroll
-		for (int i = 0; i < 4; i++) besta = (v[j][i] == mtop[j]) ? sym_of(lane, i) : besta; // slots ascend in symbol
-		const int topa = wave_max_i32(besta);
+		for (int i = 0; i < 4; i++) eqm[i] = __ballot(v[j][i] == mtop[j]);
+		const int topa = highest_sym(eqm);
 		ztop[j] = g.mul[hcoef[j] * Q + topa];
 	}
 	STAMP(1);
