@@ -483,6 +483,43 @@ def test_other_methods_frame_by_frame_at_scale(tmp_path, oracle, name, code_name
     assert 0.05 < conv.mean() <= 1.0
 
 
+@pytest.mark.parametrize("label,code_name,cons,method,B,ebn0,iters,kw,rm", [
+    ("ems_u512", "divsalar.UNBLDPC.512.256.GF.256", "BPSK", 2, 2048, 1.0, 50, dict(ems_nm=32, ems_nc=3), 1),
+    ("ems_u512_nc2", "divsalar.UNBLDPC.512.256.GF.256", "BPSK", 2, 1024, 1.0, 50, dict(ems_nm=32, ems_nc=2, ems_factor=1.2, ems_offset=0.1), 1),
+    ("tems_bds", "BDS.576.288.GF.64", "GRAY_64QAM", 4, 2048, 3.0, 50, dict(tems_nr=2, tems_nc=3), 0),
+    ("tems_bds_nr3", "BDS.576.288.GF.64", "GRAY_64QAM", 4, 1024, 3.0, 30, dict(tems_nr=3, tems_nc=2, tems_factor=1.1, tems_offset=0.05), 0),
+    ("bp_c512", "divsalar.CNBLDPC.512.256.GF.256", "GRAY_256QAM", 1, 512, 2.6, 30, dict(), 0),
+])
+def test_fused_specialised_and_general_kernels_agree_at_scale(tmp_path, label, code_name, cons, method, B, ebn0, iters, kw, rm):
+    """Three independently written GPU paths -- fused iteration (one launch), specialised check node behind the separate VN
+    pass, general kernels -- on thousands of link-chain frames across the waterfall: EMS / T-EMS are the same arithmetic, so
+    decisions, flags and iteration counts of every frame must be identical; the two log-QSPA kernels sum in different orders
+    (LLRs agree to ~1e-12), so they must agree on flags and iteration counts everywhere and on the decisions of every frame
+    that converges."""
+    from nbldpc_amd import hostlib
+    q = df.codes()[code_name]["q"]
+    hostlib.prepare_workdir(str(tmp_path), dict(gfq=q, code=code_name, method=method, max_iter=iters, parallel=B, nqam=(2 if cons == "BPSK" else q),
+                                                constellation=cons, random_msg=rm, seed=31337, **kw), code_name, cons)
+    c = df.codes()[code_name]
+    L, tx, _, _ = hostlib.frontend(str(tmp_path), ebn0, 1, c["N"], c["N"] - c["M"], c["q"], B)
+    code = nb.Code(code_name)
+    res = []
+    for variant in (0, 2, 1):
+        dec = nb.Decoder(code, method, iters, poll_every=4, **kw)
+        _force_generic(dec, variant)
+        res.append(dec.decode(L))
+        dec.close()
+    o0, c0, i0 = res[0]
+    assert 0.02 < c0.mean() < 0.999, c0.mean()  # converging and failing frames are both present
+    assert np.array_equal(o0[c0 == 1], tx[c0 == 1])
+    for o, c, i in res[1:]:
+        assert np.array_equal(c, c0) and np.array_equal(i, i0), label
+        if method == 1:
+            assert np.array_equal(o[c0 == 1], o0[c0 == 1]), label
+        else:
+            assert np.array_equal(o, o0), label
+
+
 def test_device_pointer_entry_point():
     import torch
     g, meta = load_golden("cfg2_ems_u128")
