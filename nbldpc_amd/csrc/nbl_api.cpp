@@ -90,12 +90,13 @@ static void free_workspace(nbl_decoder *d)
 }
 
 // Shapes whose whole iteration is ONE launch (variable-node pass recomputed inside the check-node kernel, c2v double-buffered):
-// (2,4)-regular codes, EMS over GF(256) with nm in {8,16,32}, T-EMS over GF(64), log-QSPA over GF(256).
+// (2,4)-regular codes, EMS over GF(256) with nm in {8,16,32}, T-EMS over GF(64) and GF(256), log-QSPA over GF(256).
 static bool fused_shape(const nbl_decoder *d)
 {
 	if (!d->all_dv2) return false;
 	if (d->prm.method == NBL_METHOD_EMS) return nbl_ems256_applicable(d->g, d->all_dc4, d->prm.ems_nm, d->prm.ems_nc);
-	if (d->prm.method == NBL_METHOD_TEMS) return nbl_tems64_applicable(d->g, d->all_dc4, d->prm.tems_nr, d->prm.tems_nc);
+	if (d->prm.method == NBL_METHOD_TEMS)
+		return nbl_tems64_applicable(d->g, d->all_dc4, d->prm.tems_nr, d->prm.tems_nc) || nbl_tems256_applicable(d->g, d->all_dc4, d->prm.tems_nr, d->prm.tems_nc);
 	if (d->prm.method == NBL_METHOD_BP) return nbl_bp256_applicable(d->g, d->all_dc4);
 	return false;
 }
@@ -317,6 +318,7 @@ static nbl_status launch_cn(nbl_decoder *d, const NblRun &r, hipStream_t st)
 		break;
 	case NBL_METHOD_TEMS:
 		if (d->force_generic != 1 && nbl_tems64_applicable(d->g, d->all_dc4, r.nr, r.nc)) HIP_TRY(d, nbl_launch_cn_tems64(d->g, d->w, r, false, st));
+		else if (d->force_generic != 1 && nbl_tems256_applicable(d->g, d->all_dc4, r.nr, r.nc)) HIP_TRY(d, nbl_launch_cn_tems256(d->g, d->w, r, false, st));
 		else HIP_TRY(d, nbl_launch_cn_tems(d->g, d->w, r, st));
 		break;
 	case NBL_METHOD_BP:
@@ -366,7 +368,8 @@ static nbl_status run_iterations(nbl_decoder *d, const double *d_Lin, int B, hip
 			wf.c2v = (it & 1) ? bufB : bufA;
 			wf.store_v2c = d->record_state ? 1 : 0;
 			if (p.method == NBL_METHOD_EMS) HIP_TRY(d, nbl_launch_cn_ems256(d->g, wf, r, true, st));
-			else if (p.method == NBL_METHOD_TEMS) HIP_TRY(d, nbl_launch_cn_tems64(d->g, wf, r, true, st));
+			else if (p.method == NBL_METHOD_TEMS && d->g.q == 64) HIP_TRY(d, nbl_launch_cn_tems64(d->g, wf, r, true, st));
+			else if (p.method == NBL_METHOD_TEMS) HIP_TRY(d, nbl_launch_cn_tems256(d->g, wf, r, true, st));
 			else HIP_TRY(d, nbl_launch_cn_bp256(d->g, wf, r, true, st));
 			HIP_TRY(d, mark(2));
 			d->launches[2]++;

@@ -26,6 +26,10 @@ hipError_t nbl_launch_cn_bp(const NblGraphDev &g, const NblWork &w, const NblRun
 bool nbl_tems64_applicable(const NblGraphDev &g, bool all_dc4, int nr, int nc);
 hipError_t nbl_launch_cn_tems64(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st);
 
+// T-EMS check node for GF(256), check degree 4 (nbl_cn_tems256.hip)
+bool nbl_tems256_applicable(const NblGraphDev &g, bool all_dc4, int nr, int nc);
+hipError_t nbl_launch_cn_tems256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st);
+
 // log-QSPA check node for GF(256), check degree 4 (nbl_cn_bp256.hip)
 bool nbl_bp256_applicable(const NblGraphDev &g, bool all_dc4);
 hipError_t nbl_launch_cn_bp256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st);

@@ -240,9 +240,11 @@ def test_random_ties_all_kernel_variants(oracle, nm, seed, nc):
         dec.close()
 
 
-@pytest.mark.parametrize("nr,nc", [(1, 1), (2, 1), (2, 2), (2, 3), (3, 2), (3, 3), (4, 3)])
-def test_tems_gf64_every_shape_ties_and_erasures_vs_oracle(oracle, nr, nc):
-    """GF(64) dc=4 T-EMS kernel (and the general kernel beside it), every (nr, nc) it accepts, state after 3 iterations
+@pytest.mark.parametrize("codename,iters,nr,nc", [("BDS.576.288.GF.64", 3, a, b) for a, b in [(1, 1), (2, 1), (2, 2), (2, 3), (3, 2), (3, 3), (4, 3)]]
+                         + [("divsalar.UNBLDPC.128.64.GF.256", 2, a, b) for a, b in [(1, 1), (2, 3), (3, 2)]])
+def test_tems_gf64_every_shape_ties_and_erasures_vs_oracle(oracle, codename, iters, nr, nc):
+    """GF(64) and GF(256) dc=4 T-EMS kernels (fused, unfused, and the general kernel beside them), every (nr, nc) they accept
+    on GF(64) and three shapes on GF(256) (the oracle enumerates 8 M paths per check there), state after 3 (2) iterations
     bit-identical to the oracle:
       * real-valued frames (one with erased symbols, one all-zero) with shaped outputs (factor, offset dead-zone);
       * integer-valued frames with factor 1 / offset 0: hundreds of EXACT ties per check (column order strict '<' :1858, first
@@ -251,11 +253,10 @@ def test_tems_gf64_every_shape_ties_and_erasures_vs_oracle(oracle, nr, nc):
     Integer inputs are not combined with a factor like 1.1: that manufactures path costs one ulp apart (2 vs 1.9999999999999998)
     whose sums round to the same value, the one case where a dynamic programme and the reference's enumeration can pick
     different (equal-cost) paths -- DESIGN.md section 3."""
-    codename = "BDS.576.288.GF.64"
     code = nb.Code(codename)
     N, M, q, ev, ec, eh = df.code_edges(codename)
     rng = np.random.default_rng(640 + 10 * nr + nc)
-    mk = lambda mode, k: oracle.Decoder(oracle.Code(edges=(N, M, q, ev, ec, eh)), oracle.GF(q), oracle.TEMS, 3, mode, **k)  # noqa: E731
+    mk = lambda mode, k: oracle.Decoder(oracle.Code(edges=(N, M, q, ev, ec, eh)), oracle.GF(q), oracle.TEMS, iters, mode, **k)  # noqa: E731
 
     def run(L, kw, modes):
         refs = []
@@ -267,14 +268,14 @@ def test_tems_gf64_every_shape_ties_and_erasures_vs_oracle(oracle, nr, nc):
                 ref.append((r, o.copy(), it, [x.copy() for x in od.state()]))
             refs.append(ref)
         for variant in (0, 1, 2):  # fused iteration, general kernels, specialised check node behind the separate VN pass
-            dec = nb.Decoder(code, nb.METHOD_TEMS, 3, **kw)
+            dec = nb.Decoder(code, nb.METHOD_TEMS, iters, **kw)
             _force_generic(dec, variant)
             dec.record_state(True)
-            out, conv, iters = dec.decode(L)
+            out, conv, its = dec.decode(L)
             for ref in refs:
                 for b in range(L.shape[0]):
                     r, o, it, st = ref[b]
-                    assert (conv[b], iters[b]) == (r, it) and np.array_equal(out[b], o), (variant, b)
+                    assert (conv[b], its[b]) == (r, it) and np.array_equal(out[b], o), (variant, b)
                     P, V, Cc = dec.read_state(b)
                     assert np.array_equal(P, st[0]) and np.array_equal(V, st[1]) and np.array_equal(Cc, st[2]), (variant, b)
             dec.close()
@@ -488,6 +489,8 @@ def test_other_methods_frame_by_frame_at_scale(tmp_path, oracle, name, code_name
     ("ems_u512_nc2", "divsalar.UNBLDPC.512.256.GF.256", "BPSK", 2, 1024, 1.0, 50, dict(ems_nm=32, ems_nc=2, ems_factor=1.2, ems_offset=0.1), 1),
     ("tems_bds", "BDS.576.288.GF.64", "GRAY_64QAM", 4, 2048, 3.0, 50, dict(tems_nr=2, tems_nc=3), 0),
     ("tems_bds_nr3", "BDS.576.288.GF.64", "GRAY_64QAM", 4, 1024, 3.0, 30, dict(tems_nr=3, tems_nc=2, tems_factor=1.1, tems_offset=0.05), 0),
+    ("tems_u512", "divsalar.UNBLDPC.512.256.GF.256", "BPSK", 4, 512, 1.4, 30, dict(tems_nr=2, tems_nc=3), 1),
+    ("tems_c256", "divsalar.CNBLDPC.256.128.GF.256", "GRAY_256QAM", 4, 512, 3.0, 20, dict(tems_nr=3, tems_nc=3, tems_factor=1.05, tems_offset=0.02), 0),
     ("bp_c512", "divsalar.CNBLDPC.512.256.GF.256", "GRAY_256QAM", 1, 512, 2.6, 30, dict(), 0),
 ])
 def test_fused_specialised_and_general_kernels_agree_at_scale(tmp_path, label, code_name, cons, method, B, ebn0, iters, kw, rm):
