@@ -122,7 +122,7 @@ def pmc_traffic(fused, B):
     if not fused or not os.path.exists(path):
         return None
     for name, v in json.load(open(path)).get("hbm_pmc", {}).items():
-        if "cn_ems_q256_dc4_kernel<32, true>" in name:
+        if "cn_ems_q256_dc4_kernel<32, true" in name:
             return v["hbm_bytes_per_launch_corrected"] * B / 16384.0
     return None
 
