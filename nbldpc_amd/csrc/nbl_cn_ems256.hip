@@ -217,7 +217,8 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 
 	double *U = (double *)smem;              // [256] check-domain copy of one input vector | histogram | S of one output
 	double *P = U + Q;                       // [256] pair convolution (U..P together: candidate buffer of the selection)
-	ListEnt *lstp = (ListEnt *)(P + Q);      // [4][NMP]  the nm best of every edge, grouped by symbol bit 0 and padded
+	// P[256..383] mirrors P[0..127] while a gather runs: the partner half of chunk `ad` is then always at ad + 1024
+	ListEnt *lstp = (ListEnt *)(P + Q + Q / 2); // [4][NMP]  the nm best of every edge, grouped by symbol bit 0 and padded
 	int *misc = (int *)(lstp + 4 * NMP);     // [4] scratch counters
 
 	unsigned long long st_t0 = 0, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -505,7 +506,11 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		}
 		__syncthreads();
 	};
-	auto pair_conv = [&](int ja, int jb) { pair_scatter(P, ja, jb, 0.0, 0); };
+	auto pair_conv = [&](int ja, int jb) {
+		pair_scatter(P, ja, jb, 0.0, 0);
+		((double2 *)P)[128 + lane] = ((const double2 *)P)[lane]; // mirror of the low half for the gathers
+		__syncthreads();
+	};
 	// Sout[s] = max(Sout[s], src[s ^ sx] + add) for the lane's four symbols
 	auto fold = [&](const double *src, int sx, double add, double (&Sout)[4]) {
 		const char *Sb = (const char *)src;
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			for (int u = 0; u < 4; u++) {
 				const int ad = lane16 ^ en[u].tt;
 				ra[u] = *(const double2 *)(Pb + ad);
-				rb[u] = *(const double2 *)(Pb + (ad ^ 1024));
+				rb[u] = *(const double2 *)(Pb + ad + 1024); // the other half (P[256..383] mirrors P[0..127])
 			}
 #pragma unroll
 			for (int u = 0; u < 4; u++) {
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			for (int u = 0; u < 4; u++) {
 				const int ad = lane16 ^ en[u].tt;
 				ra[u] = *(const double2 *)(Pb + ad);
-				rb[u] = *(const double2 *)(Pb + (ad ^ 1024));
+				rb[u] = *(const double2 *)(Pb + ad + 1024); // the other half (P[256..383] mirrors P[0..127])
 			}
 #pragma unroll
 			for (int u = 0; u < 4; u++) {
@@ -659,7 +664,7 @@ bool nbl_ems256_applicable(const NblGraphDev &g, bool all_dc4, int nm, int nc)
 	return g.q == 256 && all_dc4 && nc >= 1 && (nm == 8 || nm == 16 || nm == 32);
 }
 
-size_t nbl_ems256_lds_bytes(int nm) { return 2 * Q * 8 + (size_t)4 * (nm + 8) * 16 + 16; }
+size_t nbl_ems256_lds_bytes(int nm) { return 2 * Q * 8 + Q / 2 * 8 + (size_t)4 * (nm + 8) * 16 + 16; }
 
 template <int NM, bool FUSED>
 static void launch_nc(int nc, dim3 grid, dim3 block, size_t lds, hipStream_t st, const NblGraphDev &g, const NblWork &w, const NblRun &r)
