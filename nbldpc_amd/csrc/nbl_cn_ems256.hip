@@ -204,7 +204,9 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 {
 	constexpr int LOGNM = (NM == 8) ? 3 : (NM == 16) ? 4 : 5;
 	constexpr int NMP = NM + 8; // padded list: [even-symbol group | pad to 4 | odd-symbol group | pad to 4]
-	extern __shared__ __attribute__((aligned(16))) char smem[];
+	// static LDS: its base is a compile-time constant, so computed addresses fold into the ds_* offset fields (with `extern
+	// __shared__` every computed address pays a v_add with the link-time base)
+	__shared__ __attribute__((aligned(16))) char smem[2 * Q * 8 + Q / 2 * 8 + 4 * (NM + 8) * 16 + 16];
 	const int lane = lane_id();
 	// XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  All checks of
 	// a codeword are given to ONE XCD, so the second read of every L_ch / c2v vector (each is used by two checks) can hit
@@ -669,9 +671,9 @@ size_t nbl_ems256_lds_bytes(int nm) { return 2 * Q * 8 + Q / 2 * 8 + (size_t)4 *
 template <int NM, bool FUSED>
 static void launch_nc(int nc, dim3 grid, dim3 block, size_t lds, hipStream_t st, const NblGraphDev &g, const NblWork &w, const NblRun &r)
 {
-	if (nc >= 3) cn_ems_q256_dc4_kernel<NM, FUSED, 3><<<grid, block, lds, st>>>(g, w, r);
-	else if (nc == 2) cn_ems_q256_dc4_kernel<NM, FUSED, 2><<<grid, block, lds, st>>>(g, w, r);
-	else cn_ems_q256_dc4_kernel<NM, FUSED, 1><<<grid, block, lds, st>>>(g, w, r);
+	if (nc >= 3) cn_ems_q256_dc4_kernel<NM, FUSED, 3><<<grid, block, 0, st>>>(g, w, r);
+	else if (nc == 2) cn_ems_q256_dc4_kernel<NM, FUSED, 2><<<grid, block, 0, st>>>(g, w, r);
+	else cn_ems_q256_dc4_kernel<NM, FUSED, 1><<<grid, block, 0, st>>>(g, w, r);
 }
 
 hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
