@@ -12,8 +12,9 @@ decodes its own batch (independent frames, no data-path collective: SURVEY 8e), 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline      dominant kernel (EMS check node): algorithmic bytes per launch / mean launch time (HIP events on
                 the launch stream inside the timed region) against the 8 TB/s HBM peak
-  cpu_baseline  the oracle's literal restatement of the reference algorithm, timed on this host's cores on a
-                bounded sample of the same workload (rank 0, N=1 only)
+  cpu_baseline  the compiled reference itself (oracle/_ref, kind "reference") timed on this host's cores on a bounded
+                sample of the same workload (rank 0, N=1 only); cpu_baseline_port = the oracle's literal restatement
+                on codewords of the same batch (kind "port"; also the fallback when oracle/_ref is absent)
 """
 import argparse
 import json
