@@ -122,7 +122,11 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 		for (int attempt = 0;; attempt++) {
 			int nex[4];
 #pragma unroll
-			for (int i = 0; i < 4; i++) { nex[i] = -ex[i]; acc[i] = 0.0; }
+			for (int i = 0; i < 4; i++) {
+				nex[i] = -ex[i];
+				asm("" : "+v"(nex[i])); // opaque: keeps the compiler from folding the negation back into a sub + add pair
+				acc[i] = 0.0;
+			}
 #pragma unroll 2
 			for (int g = 0; g < 64; g++) {
 				const double2 a01 = s.Am01[g], a23 = s.Am23[g];
@@ -134,8 +138,7 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 				for (int j = 0; j < 4; j++)
 #pragma unroll
 					for (int i = 0; i < 4; i++) {
-						int d; // exact power-of-two scaling, far below the range gives 0
-						asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(ae[j]), "v"(be[i ^ j]), "v"(nex[i]));
+						const int d = ae[j] + be[i ^ j] + nex[i]; // one v_add3_u32; exact power-of-two scaling, far below the range gives 0
 						acc[i] = __fma_rn(a[j], ldexp(b[i ^ j], d), acc[i]);
 					}
 			}
