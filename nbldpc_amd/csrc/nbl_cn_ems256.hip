@@ -223,10 +223,18 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	ListEnt *lstp = (ListEnt *)(P + Q + Q / 2); // [4][NMP]  the nm best of every edge, grouped by symbol bit 0 and padded
 	int *misc = (int *)(lstp + 4 * NMP);     // [4] scratch counters
 
+	// per-section cycle stamps (tools/stamps.py): compiled in only with -DNBL_EMS_STAMPS -- the thirteen 64-bit accumulators
+	// live in SGPRs for the whole kernel and push the selection code into SGPR spills
+#ifdef NBL_EMS_STAMPS
 	unsigned long long st_t0 = 0, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	const bool st_on = (w.stamps != nullptr) && ((blockIdx.x & 63) == 0);
 #define STAMP(i) do { if (st_on) { unsigned long long t1_ = clock64(); st_acc[i] += t1_ - st_t0; st_t0 = t1_; } } while (0)
+#define STAMP_COUNT(i) do { if (st_on) st_acc[i]++; } while (0)
 	if (st_on) st_t0 = clock64();
+#else
+#define STAMP(i) do { } while (0)
+#define STAMP_COUNT(i) do { } while (0)
+#endif
 
 	const double *V = w.v2c + (size_t)b * g.E * Q;
 	double *C = w.c2v + ((size_t)b * g.E + c0) * Q;
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 				ss.done = 0;
 				for (int guard = 0; guard < 300 && !ss.done; guard++) {
 					select_step(v[j], NM, ss);
-					if (st_on) st_acc[9]++;
+					STAMP_COUNT(9);
 				}
 				finish_members(ss, NM, member);
 			}
@@ -653,11 +661,14 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		STAMP(8);
 	}
 
+#ifdef NBL_EMS_STAMPS
 	if (st_on && lane == 0) {
 		for (int i = 0; i < 12; i++) atomicAdd(&w.stamps[i], st_acc[i]);
 		atomicAdd(&w.stamps[15], 1ull);
 	}
+#endif
 #undef STAMP
+#undef STAMP_COUNT
 #undef TSYM
 }
 

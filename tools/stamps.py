@@ -1,4 +1,8 @@
-"""Diagnostic: in-kernel cycle breakdown of the EMS check-node kernel (not a benchmark)."""
+"""Diagnostic: in-kernel cycle breakdown of the EMS check-node kernel (not a benchmark).
+
+Needs the stamps build of the library:  make -C nbldpc_amd/csrc stamps  &&
+NBL_HIP_LIB=$PWD/nbldpc_amd/csrc/ab/libnbldpc_hip_stamps.so python tools/stamps.py
+(the default build leaves the stamps out: their accumulators cost 26 SGPRs and push the kernel into SGPR spills)."""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
