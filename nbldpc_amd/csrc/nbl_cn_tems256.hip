@@ -38,7 +38,9 @@ __device__ __forceinline__ double pick(const double (&u)[DC], int k)
 	return k == 0 ? u[0] : k == 1 ? u[1] : k == 2 ? u[2] : u[3];
 }
 
-template <bool FUSED>
+// NC = the deviation budget tems_nc (1..3) as a template parameter: with a run-time nc the layer-3 update sits behind a branch
+// in the candidate loop and the 16-byte predecessor loads are split in two
+template <bool FUSED, int NC>
 __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	__shared__ double dU[DC][Q];                                  // delta-domain trellis (:1814-1834)
@@ -52,7 +54,8 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 	const int b = blockIdx.x / g.M, m = blockIdx.x % g.M;
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m];
-	const int nr = r.nr, nc = r.nc;
+	const int nr = r.nr;
+	constexpr int nc = NC;
 	double *V = w.v2c + (size_t)b * g.E * Q;
 	double *C = w.c2v + ((size_t)b * g.E + c0) * Q;
 
@@ -145,14 +148,15 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 
 	// ---- 3. min-plus dynamic programme over the columns; v[l], c[l] = best path with exactly l deviating columns -----------
 	const double INF = __builtin_huge_val();
-	double v1[NS], v2[NS], v3[NS];
-	unsigned c1[NS], c2[NS], c3[NS];
+	// (an array of structs with interleaved field types on purpose: six parallel arrays are promoted to <4 x double> / <4 x i32>
+	// vector values, and hipcc 7.2's late GVN over those then yields wrong path codes on tie-heavy inputs at -O2 and above)
+	struct DpState { double v1; unsigned c1; double v2; unsigned c2; double v3; unsigned c3; } st[NS];
 #pragma unroll
 	for (int i = 0; i < NS; i++) {
-		v1[i] = v2[i] = v3[i] = INF;
-		c1[i] = c2[i] = c3[i] = 0;
+		st[i].v1 = st[i].v2 = st[i].v3 = INF;
+		st[i].c1 = st[i].c2 = st[i].c3 = 0;
 		const int s = lane + 64 * i;
-		if ((mask[i] & 1) && s > 0) { v1[i] = u[i][0]; c1[i] = (unsigned)s << (P * (DC - 1)); }
+		if ((mask[i] & 1) && s > 0) { st[i].v1 = u[i][0]; st[i].c1 = (unsigned)s << (P * (DC - 1)); }
 	}
 	const int lane16 = lane << 4;
 #pragma unroll
@@ -163,8 +167,8 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 #pragma unroll
 		for (int i = 0; i < NS; i++) {
 			const int s = lane + 64 * i;
-			Sv[s] = make_double2(v1[i], v2[i]);
-			Sc[s] = make_uint4(c1[i], c2[i], 0u, 0u);
+			Sv[s] = make_double2(st[i].v1, st[i].v2);
+			Sc[s] = make_uint4(st[i].c1, st[i].c2, 0u, 0u);
 			const bool c = ((mask[i] >> d) & 1) && s > 0;
 			const uint64_t bal = __ballot(c);
 			if (c) {
@@ -198,8 +202,8 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 						const int off = A ^ (i << 10);
 						const double2 sv = *(const double2 *)(Sraw + off);
 						const uint2 sc = *(const uint2 *)(Sraw + Q * 16 + off);
-						relax(v2[i], c2[i], sv.x + e[t].u, sc.x + e[t].dig);
-						if (d >= 2 && nc >= 3) relax(v3[i], c3[i], sv.y + e[t].u, sc.y + e[t].dig);
+						relax(st[i].v2, st[i].c2, sv.x + e[t].u, sc.x + e[t].dig);
+						if (d >= 2 && nc >= 3) relax(st[i].v3, st[i].c3, sv.y + e[t].u, sc.y + e[t].dig);
 					}
 				}
 			}
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 #pragma unroll
 		for (int i = 0; i < NS; i++) {
 			const int s = lane + 64 * i;
-			if (((mask[i] >> d) & 1) && s > 0) relax(v1[i], c1[i], u[i][d], (unsigned)s << sh);
+			if (((mask[i] >> d) & 1) && s > 0) relax(st[i].v1, st[i].c1, u[i][d], (unsigned)s << sh);
 		}
 		__syncthreads();
 	}
@@ -220,9 +224,9 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 		eta[i] = 0xffffffffu;
 		const double v0 = (lane == 0 && i == 0) ? 0.0 : INF;
 		if (v0 < dW[i] || (v0 == dW[i] && 0u < eta[i])) { dW[i] = v0; eta[i] = 0u; }
-		if (nc >= 1 && (v1[i] < dW[i] || (v1[i] == dW[i] && c1[i] < eta[i]))) { dW[i] = v1[i]; eta[i] = c1[i]; }
-		if (nc >= 2 && (v2[i] < dW[i] || (v2[i] == dW[i] && c2[i] < eta[i]))) { dW[i] = v2[i]; eta[i] = c2[i]; }
-		if (nc >= 3 && (v3[i] < dW[i] || (v3[i] == dW[i] && c3[i] < eta[i]))) { dW[i] = v3[i]; eta[i] = c3[i]; }
+		if (nc >= 1 && (st[i].v1 < dW[i] || (st[i].v1 == dW[i] && st[i].c1 < eta[i]))) { dW[i] = st[i].v1; eta[i] = st[i].c1; }
+		if (nc >= 2 && (st[i].v2 < dW[i] || (st[i].v2 == dW[i] && st[i].c2 < eta[i]))) { dW[i] = st[i].v2; eta[i] = st[i].c2; }
+		if (nc >= 3 && (st[i].v3 < dW[i] || (st[i].v3 == dW[i] && st[i].c3 < eta[i]))) { dW[i] = st[i].v3; eta[i] = st[i].c3; }
 	}
 
 	// ---- 4. outputs of the four edges (Lc overlays the predecessor records: the last barrier above has passed) -------------
@@ -273,7 +277,14 @@ bool nbl_tems256_applicable(const NblGraphDev &g, bool all_dc4, int nr, int nc)
 hipError_t nbl_launch_cn_tems256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 {
 	dim3 grid((unsigned)((long long)r.B * g.M)), block(64);
-	if (fused) cn_tems_q256_dc4_kernel<true><<<grid, block, 0, st>>>(g, w, r);
-	else cn_tems_q256_dc4_kernel<false><<<grid, block, 0, st>>>(g, w, r);
+	switch ((fused ? 4 : 0) + r.nc) {
+	case 1: cn_tems_q256_dc4_kernel<false, 1><<<grid, block, 0, st>>>(g, w, r); break;
+	case 2: cn_tems_q256_dc4_kernel<false, 2><<<grid, block, 0, st>>>(g, w, r); break;
+	case 3: cn_tems_q256_dc4_kernel<false, 3><<<grid, block, 0, st>>>(g, w, r); break;
+	case 5: cn_tems_q256_dc4_kernel<true, 1><<<grid, block, 0, st>>>(g, w, r); break;
+	case 6: cn_tems_q256_dc4_kernel<true, 2><<<grid, block, 0, st>>>(g, w, r); break;
+	case 7: cn_tems_q256_dc4_kernel<true, 3><<<grid, block, 0, st>>>(g, w, r); break;
+	default: return hipErrorInvalidValue;
+	}
 	return hipGetLastError();
 }

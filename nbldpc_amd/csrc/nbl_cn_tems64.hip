@@ -36,7 +36,9 @@ __device__ __forceinline__ double pick(const double (&u)[DC], int k)
 	return k == 0 ? u[0] : k == 1 ? u[1] : k == 2 ? u[2] : u[3];
 }
 
-template <bool FUSED>
+// NC = the deviation budget tems_nc (1..3) as a template parameter: with a run-time nc the layer-3 update sits behind a branch
+// in the candidate loop and the 16-byte predecessor loads are split in two
+template <bool FUSED, int NC>
 __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	__shared__ double dU[DC][Q];                            // delta-domain trellis (:1814-1834)
@@ -48,7 +50,8 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 	const int b = blockIdx.x / g.M, m = blockIdx.x % g.M;
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m];
-	const int nr = r.nr, nc = r.nc;
+	const int nr = r.nr;
+	constexpr int nc = NC;
 	double *V = w.v2c + (size_t)b * g.E * Q;
 	double *C = w.c2v + ((size_t)b * g.E + c0) * Q;
 
@@ -224,7 +227,14 @@ bool nbl_tems64_applicable(const NblGraphDev &g, bool all_dc4, int nr, int nc)
 hipError_t nbl_launch_cn_tems64(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 {
 	dim3 grid((unsigned)((long long)r.B * g.M)), block(64);
-	if (fused) cn_tems_q64_dc4_kernel<true><<<grid, block, 0, st>>>(g, w, r);
-	else cn_tems_q64_dc4_kernel<false><<<grid, block, 0, st>>>(g, w, r);
+	switch ((fused ? 4 : 0) + r.nc) {
+	case 1: cn_tems_q64_dc4_kernel<false, 1><<<grid, block, 0, st>>>(g, w, r); break;
+	case 2: cn_tems_q64_dc4_kernel<false, 2><<<grid, block, 0, st>>>(g, w, r); break;
+	case 3: cn_tems_q64_dc4_kernel<false, 3><<<grid, block, 0, st>>>(g, w, r); break;
+	case 5: cn_tems_q64_dc4_kernel<true, 1><<<grid, block, 0, st>>>(g, w, r); break;
+	case 6: cn_tems_q64_dc4_kernel<true, 2><<<grid, block, 0, st>>>(g, w, r); break;
+	case 7: cn_tems_q64_dc4_kernel<true, 3><<<grid, block, 0, st>>>(g, w, r); break;
+	default: return hipErrorInvalidValue;
+	}
 	return hipGetLastError();
 }

@@ -492,6 +492,12 @@ def test_other_methods_frame_by_frame_at_scale(tmp_path, oracle, name, code_name
     ("tems_u512", "divsalar.UNBLDPC.512.256.GF.256", "BPSK", 4, 512, 1.4, 30, dict(tems_nr=2, tems_nc=3), 1),
     ("tems_c256", "divsalar.CNBLDPC.256.128.GF.256", "GRAY_256QAM", 4, 512, 3.0, 20, dict(tems_nr=3, tems_nc=3, tems_factor=1.05, tems_offset=0.02), 0),
     ("bp_c512", "divsalar.CNBLDPC.512.256.GF.256", "GRAY_256QAM", 1, 512, 2.6, 30, dict(), 0),
+    # channel LLRs rounded to integers: exact ties in every comparison of every kernel, at scale
+    ("int_tems_bds", "BDS.576.288.GF.64", "GRAY_64QAM", 4, 2048, 3.0, 30, dict(tems_nr=2, tems_nc=3), 0),
+    ("int_tems_bds_nr3", "BDS.576.288.GF.64", "GRAY_64QAM", 4, 1024, 3.0, 30, dict(tems_nr=3, tems_nc=3), 0),
+    ("int_tems_u128", "divsalar.UNBLDPC.128.64.GF.256", "BPSK", 4, 1024, 2.0, 20, dict(tems_nr=2, tems_nc=3), 1),
+    ("int_tems_u128_nc2", "divsalar.UNBLDPC.128.64.GF.256", "BPSK", 4, 1024, 2.0, 20, dict(tems_nr=3, tems_nc=2), 1),
+    ("int_ems_u512", "divsalar.UNBLDPC.512.256.GF.256", "BPSK", 2, 1024, 1.0, 30, dict(ems_nm=32, ems_nc=3), 1),
 ])
 def test_fused_specialised_and_general_kernels_agree_at_scale(tmp_path, label, code_name, cons, method, B, ebn0, iters, kw, rm):
     """Three independently written GPU paths -- fused iteration (one launch), specialised check node behind the separate VN
@@ -505,6 +511,8 @@ def test_fused_specialised_and_general_kernels_agree_at_scale(tmp_path, label, c
                                                 constellation=cons, random_msg=rm, seed=31337, **kw), code_name, cons)
     c = df.codes()[code_name]
     L, tx, _, _ = hostlib.frontend(str(tmp_path), ebn0, 1, c["N"], c["N"] - c["M"], c["q"], B)
+    if label.startswith("int_"):
+        L = np.round(L)
     code = nb.Code(code_name)
     res = []
     for variant in (0, 2, 1):
@@ -514,7 +522,8 @@ def test_fused_specialised_and_general_kernels_agree_at_scale(tmp_path, label, c
         dec.close()
     o0, c0, i0 = res[0]
     assert 0.02 < c0.mean() < 0.999, c0.mean()  # converging and failing frames are both present
-    assert np.array_equal(o0[c0 == 1], tx[c0 == 1])
+    if not label.startswith("int_"):
+        assert np.array_equal(o0[c0 == 1], tx[c0 == 1])
     for o, c, i in res[1:]:
         assert np.array_equal(c, c0) and np.array_equal(i, i0), label
         if method == 1:
