@@ -142,6 +142,9 @@ template <int NS> __device__ __forceinline__ int wave_decide(const double (&v)[N
 // check-to-variable shaping, NBLDPC.cpp:903-916 / 1113-1126
 __device__ __forceinline__ double shape_llr(double y, double factor, double offset)
 {
+	// unshaped (factor 1, offset 0 -- the values of the reference's sample profile): the dead zone is the single point 0, and
+	// NaN maps to 0 as below
+	if (factor == 1.0 && offset == 0.0) return (y < 0.0 || y > 0.0) ? y : 0.0;
 	if (factor != 1.0) y = y / factor;
 	if (y < -1 * offset) return y + offset;
 	if (y > offset) return y - offset;
