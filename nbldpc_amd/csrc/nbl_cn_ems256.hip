@@ -8,7 +8,7 @@
 //     max-plus XOR-gather "P[s ^ t]" is two conflict-free ds_read_b128 (natural layout, lane XOR only permutes the
 //     16-byte slots inside one 256-byte LDS row).
 //   * the four conf(q,1) result vectors stay in registers; 2 KB LDS buffers U (also histogram / S staging) and P plus
-//     the packed lists -> 6.7 KB per wave at nm = 32, four waves per SIMD (VGPR-limited).
+//     the packed lists -> 7 KB per wave at nm = 32, four waves per SIMD (VGPR-limited).
 //   * the nm-best lists are packed {value, symbol} 16-byte entries, split by bit 0 of the symbol so the pair swap
 //     of the gather is resolved by loop structure instead of per-element selects.
 //   * top-nm selection without sorting: a 256-bucket histogram (LDS atomics + DPP prefix sum) finds the bucket that
@@ -16,6 +16,7 @@
 //     quickselect inside the bucket finds the exact cut under SortLLRVector's order (value desc, higher symbol first
 //     among equals).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "nbl_device.h"
 #include "nbl_kernels.h"
 
@@ -203,10 +204,10 @@ template <int NM, bool FUSED, int NC>
 __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	constexpr int LOGNM = (NM == 8) ? 3 : (NM == 16) ? 4 : 5;
-	constexpr int NMP = NM + 8; // padded list: [even-symbol group | pad to 4 | odd-symbol group | pad to 4]
+	constexpr int NMP = NM; // list stride per edge: [even-symbol group | odd-symbol group], back to back
 	// static LDS: its base is a compile-time constant, so computed addresses fold into the ds_* offset fields (with `extern
 	// __shared__` every computed address pays a v_add with the link-time base)
-	__shared__ __attribute__((aligned(16))) char smem[2 * Q * 8 + Q / 2 * 8 + 4 * (NM + 8) * 16 + 16];
+	__shared__ __attribute__((aligned(16))) char smem[2 * Q * 8 + Q / 2 * 8 + 4 * NM * 16];
 	const int lane = lane_id();
 	// XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  All checks of
 	// a codeword are given to ONE XCD, so the second read of every L_ch / c2v vector (each is used by two checks) can hit
@@ -220,8 +221,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	double *U = (double *)smem;              // [256] check-domain copy of one input vector | histogram | S of one output
 	double *P = U + Q;                       // [256] pair convolution (U..P together: candidate buffer of the selection)
 	// P[256..383] mirrors P[0..127] while a gather runs: the partner half of chunk `ad` is then always at ad + 1024
-	ListEnt *lstp = (ListEnt *)(P + Q + Q / 2); // [4][NMP]  the nm best of every edge, grouped by symbol bit 0 and padded
-	int *misc = (int *)(lstp + 4 * NMP);     // [4] scratch counters
+	ListEnt *lstp = (ListEnt *)(P + Q + Q / 2); // [4][NM]  the nm best of every edge, grouped by symbol bit 0
 
 	// per-section cycle stamps (tools/stamps.py): compiled in only with -DNBL_EMS_STAMPS -- the thirteen 64-bit accumulators
 	// live in SGPRs for the whole kernel and push the selection code into SGPR spills
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	// (a) a 256-bucket histogram of [lmin, mtop] (LDS atomics + DPP prefix sum) finds the bucket that holds the nm-th best
 	// value -- bucketing only has to be monotone, so its arithmetic needs no care; (b) a ballot quickselect, restricted to
 	// that bucket, finds the cut exactly; ties at the cut are resolved by symbol, higher first (:1731).
-	int n0[4] = {0, 0, 0, 0}, n0p[4] = {0, 0, 0, 0}, n1p[4] = {0, 0, 0, 0};
+	int n0[4] = {0, 0, 0, 0}; // entries with an even check-domain symbol per edge (they come first in the list)
 	if (NC >= 2) { // conf(nm,1) needs no lists: it is contained in conf(q,1)
 		int bk[4][4];
 		int *H = (int *)U; // [256 buckets][4 edges] (spans U and P); lane l reads buckets 4l .. 4l+3
@@ -371,8 +371,8 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			hc[i][0] = h4.x; hc[i][1] = h4.y; hc[i][2] = h4.z; hc[i][3] = h4.w;
 		}
 		STAMP(2);
-		// per edge: locate the cut bucket, settle the members, compact them into the padded list image
-		// [even-symbol group | pad to 4 | odd-symbol group | pad to 4] (pads carry -inf and never win a max)
+		// per edge: locate the cut bucket, settle the members, compact them into the list image
+		// [even-symbol group | odd-symbol group]
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const int tot = hc[0][j] + hc[1][j] + hc[2][j] + hc[3][j];
@@ -411,20 +411,8 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 				c0n += __popcll(g0[i]);
 			}
 			n0[j] = c0n;
-			n0p[j] = (c0n + 3) & ~3;
-			n1p[j] = (NM - c0n + 3) & ~3;
 			ListEnt *Lj = lstp + j * NMP;
-			if (lane < 8) {
-				ListEnt pe;
-				pe.v = NBL_NEG_INF;
-				pe.t = 0;
-				pe.tt = 0;
-				const int n1 = NM - c0n;
-				const int pos = (lane < 4) ? c0n + lane : n0p[j] + n1 + (lane - 4);
-				const bool need = (lane < 4) ? (c0n + lane < n0p[j]) : (n1 + lane - 4 < n1p[j]);
-				if (need) Lj[pos] = pe;
-			}
-			int base0 = 0, base1 = n0p[j];
+			int base0 = 0, base1 = c0n; // [even-symbol group | odd-symbol group], back to back
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
 				const int sym = TSYM(j, i);
@@ -487,32 +475,27 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		ninf.y = NBL_NEG_INF;
 		((double2 *)dst)[lane] = ninf;
 		((double2 *)dst)[64 + lane] = ninf;
-		// entry k of the contiguous member list lives at k (even group) or k - n0 + n0p (odd group) of the padded image
-		const int ka = lane & (NM - 1);
-		ListEnt ea = lstp[ja * NMP + (ka < n0[ja] ? ka : ka - n0[ja] + n0p[ja])];
+		ListEnt ea = lstp[ja * NMP + (lane & (NM - 1))];
 		ea.v = ea.v + bias;
 		ea.t ^= sxor;
 		__syncthreads();
 		constexpr int PER = 64 >> LOGNM, ROUNDS = (NM << LOGNM) >> 6;
 #pragma unroll
 		for (int it = 0; it < ROUNDS; it++) {
-			const int kb = it * PER + (lane >> LOGNM);
-			const ListEnt eb = lstp[jb * NMP + (kb < n0[jb] ? kb : kb - n0[jb] + n0p[jb])];
+			const ListEnt eb = lstp[jb * NMP + it * PER + (lane >> LOGNM)];
 			__hip_atomic_fetch_max(&dst[ea.t ^ eb.t], ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 		__syncthreads();
 	};
 	// same, accumulating into dst without clearing it
 	auto pair_scatter_more = [&](double *dst, int ja, int jb, double bias, int sxor) {
-		const int ka = lane & (NM - 1);
-		ListEnt ea = lstp[ja * NMP + (ka < n0[ja] ? ka : ka - n0[ja] + n0p[ja])];
+		ListEnt ea = lstp[ja * NMP + (lane & (NM - 1))];
 		ea.v = ea.v + bias;
 		ea.t ^= sxor;
 		constexpr int PER = 64 >> LOGNM, ROUNDS = (NM << LOGNM) >> 6;
 #pragma unroll
 		for (int it = 0; it < ROUNDS; it++) {
-			const int kb = it * PER + (lane >> LOGNM);
-			const ListEnt eb = lstp[jb * NMP + (kb < n0[jb] ? kb : kb - n0[jb] + n0p[jb])];
+			const ListEnt eb = lstp[jb * NMP + it * PER + (lane >> LOGNM)];
 			__hip_atomic_fetch_max(&dst[ea.t ^ eb.t], ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 		__syncthreads();
@@ -548,45 +531,42 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		double a0 = NBL_NEG_INF, a1 = NBL_NEG_INF, a2 = NBL_NEG_INF, a3 = NBL_NEG_INF;
 		const char *Pb = (const char *)P;
 		const ListEnt *L = lstp + jc * NMP;
-		const int e0 = n0p[jc], e1 = n0p[jc] + n1p[jc];
-		for (int k = 0; k < e0; k += 4) {
-			ListEnt en[4];
-			double2 ra[4], rb[4];
+		// entries [0, n0): even symbols, the lane's slot pairs line up; [n0, NM): odd symbols, the pairs are swapped.  Four entries
+		// per trip, then the remainder one by one (no padding entries: every trip is real work)
+		auto run = [&](int k0, int k1, auto swapped) {
+			constexpr bool SW = decltype(swapped)::value;
+			int k = k0;
+			for (; k + 4 <= k1; k += 4) {
+				ListEnt en[4];
+				double2 ra[4], rb[4];
 #pragma unroll
-			for (int u = 0; u < 4; u++) en[u] = L[k + u]; // same address in every lane: LDS broadcast
+				for (int u = 0; u < 4; u++) en[u] = L[k + u]; // same address in every lane: LDS broadcast
 #pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const int ad = lane16 ^ en[u].tt;
-				ra[u] = *(const double2 *)(Pb + ad);
-				rb[u] = *(const double2 *)(Pb + ad + 1024); // the other half (P[256..383] mirrors P[0..127])
+				for (int u = 0; u < 4; u++) {
+					const int ad = lane16 ^ en[u].tt;
+					ra[u] = *(const double2 *)(Pb + ad);
+					rb[u] = *(const double2 *)(Pb + ad + 1024); // the other half (P[256..383] mirrors P[0..127])
+				}
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					a0 = dmax(a0, (SW ? ra[u].y : ra[u].x) + en[u].v);
+					a1 = dmax(a1, (SW ? ra[u].x : ra[u].y) + en[u].v);
+					a2 = dmax(a2, (SW ? rb[u].y : rb[u].x) + en[u].v);
+					a3 = dmax(a3, (SW ? rb[u].x : rb[u].y) + en[u].v);
+				}
 			}
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				a0 = dmax(a0, ra[u].x + en[u].v);
-				a1 = dmax(a1, ra[u].y + en[u].v);
-				a2 = dmax(a2, rb[u].x + en[u].v);
-				a3 = dmax(a3, rb[u].y + en[u].v);
+			for (; k < k1; k++) {
+				const ListEnt en = L[k];
+				const int ad = lane16 ^ en.tt;
+				const double2 ra = *(const double2 *)(Pb + ad), rb = *(const double2 *)(Pb + ad + 1024);
+				a0 = dmax(a0, (SW ? ra.y : ra.x) + en.v);
+				a1 = dmax(a1, (SW ? ra.x : ra.y) + en.v);
+				a2 = dmax(a2, (SW ? rb.y : rb.x) + en.v);
+				a3 = dmax(a3, (SW ? rb.x : rb.y) + en.v);
 			}
-		}
-		for (int k = e0; k < e1; k += 4) {
-			ListEnt en[4];
-			double2 ra[4], rb[4];
-#pragma unroll
-			for (int u = 0; u < 4; u++) en[u] = L[k + u];
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const int ad = lane16 ^ en[u].tt;
-				ra[u] = *(const double2 *)(Pb + ad);
-				rb[u] = *(const double2 *)(Pb + ad + 1024); // the other half (P[256..383] mirrors P[0..127])
-			}
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				a0 = dmax(a0, ra[u].y + en[u].v);
-				a1 = dmax(a1, ra[u].x + en[u].v);
-				a2 = dmax(a2, rb[u].y + en[u].v);
-				a3 = dmax(a3, rb[u].x + en[u].v);
-			}
-		}
+		};
+		run(0, n0[jc], std::false_type{});
+		run(n0[jc], NM, std::true_type{});
 		Sout[0] = dmax(Sout[0], a0);
 		Sout[1] = dmax(Sout[1], a1);
 		Sout[2] = dmax(Sout[2], a2);
@@ -678,7 +658,7 @@ bool nbl_ems256_applicable(const NblGraphDev &g, bool all_dc4, int nm, int nc)
 	return g.q == 256 && all_dc4 && nc >= 1 && (nm == 8 || nm == 16 || nm == 32);
 }
 
-size_t nbl_ems256_lds_bytes(int nm) { return 2 * Q * 8 + Q / 2 * 8 + (size_t)4 * (nm + 8) * 16 + 16; }
+size_t nbl_ems256_lds_bytes(int nm) { return 2 * Q * 8 + Q / 2 * 8 + (size_t)4 * nm * 16; }
 
 template <int NM, bool FUSED>
 static void launch_nc(int nc, dim3 grid, dim3 block, size_t lds, hipStream_t st, const NblGraphDev &g, const NblWork &w, const NblRun &r)
