@@ -76,12 +76,12 @@ template <typename T> static nbl_status upload(nbl_decoder *d, const std::vector
 
 static void free_workspace(nbl_decoder *d)
 {
-	void *ptrs[] = {d->w.Lch, d->w.v2c, d->w.c2v, d->w.post, d->w.dec, d->w.out, d->w.iters, d->w.done, d->d_Lin, d->d_conv8, d->c2v_alt};
+	void *ptrs[] = {d->w.Lch, d->w.v2c, d->w.c2v, d->w.post, d->w.dec, d->w.out, d->w.iters, d->w.done, d->d_Lin, d->d_conv8, d->c2v_alt, d->w.edge_dec};
 	d->c2v_alt = nullptr;
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	d->w.Lch = d->w.v2c = d->w.c2v = d->w.post = nullptr;
-	d->w.dec = d->w.out = d->w.iters = nullptr;
+	d->w.dec = d->w.out = d->w.iters = d->w.edge_dec = nullptr;
 	d->w.done = nullptr;
 	d->d_Lin = nullptr;
 	d->d_conv8 = nullptr;
@@ -118,6 +118,7 @@ static nbl_status ensure_workspace(nbl_decoder *d, int B)
 	if (fused_shape(d)) HIP_TRY(d, alloc((void **)&d->c2v_alt, (size_t)cap * E * q * 8));
 	if (d->record_state) HIP_TRY(d, alloc((void **)&d->w.post, (size_t)cap * N * q * 8));
 	HIP_TRY(d, alloc((void **)&d->w.dec, (size_t)cap * N * 4));
+	if (d->prm.method != NBL_METHOD_EMS) HIP_TRY(d, alloc((void **)&d->w.edge_dec, (size_t)cap * E * 4));
 	HIP_TRY(d, alloc((void **)&d->w.out, (size_t)cap * N * 4));
 	HIP_TRY(d, alloc((void **)&d->w.iters, (size_t)cap * 4));
 	HIP_TRY(d, alloc((void **)&d->w.done, (size_t)cap));

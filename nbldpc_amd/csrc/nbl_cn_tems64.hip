@@ -58,19 +58,25 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 	// ---- 0. FUSED: the variable-node pass of this iteration for the four incoming edges (NBLDPC.cpp:977-992, :1029-1052) ----
 	// post = (L_ch + c2v_0) + c2v_1 of the edge's variable (dv = 2), hard decision by the check that holds the variable's
 	// first edge, v2c = post - c2v of this edge, damped 1/4 : 3/4 against the previous v2c when its hard decision moves.
-	double vin[DC];
+	// The hard decision of the previous v2c is not recomputed from the vector: it is what step 1 below found for that vector in
+	// the previous iteration (w.edge_dec), so the previous v2c itself is only loaded when the decision moved (or in iteration 1,
+	// where it is L_ch and nothing has been recorded yet).
+	double vin[DC], vmax[DC];
+	int varg[DC];
 	if (FUSED) {
 		const double *Cp = w.c2v_prev + (size_t)b * g.E * Q;
 		double l[DC], ca[DC], cb[DC], ov[DC];
-		int nvar[DC], eidx[DC];
+		int nvar[DC], eidx[DC], before[DC];
 		bool ownA[DC];
+		const bool first = (r.iter == 1);
 #pragma unroll
 		for (int d = 0; d < DC; d++) { // every load first
 			const int n = g.c_var[c0 + d], e = g.c_epos[c0 + d], e0 = g.voff[n];
 			l[d] = w.Lch[((size_t)b * g.N + n) * Q + lane];
 			ca[d] = Cp[(size_t)g.v_cpos[e0] * Q + lane];
 			cb[d] = Cp[(size_t)g.v_cpos[e0 + 1] * Q + lane];
-			ov[d] = V[(size_t)e * Q + lane];
+			ov[d] = first ? V[(size_t)e * Q + lane] : 0.0;
+			before[d] = first ? 0 : w.edge_dec[(size_t)b * g.E + e];
 			nvar[d] = n; eidx[d] = e; ownA[d] = (e == e0);
 		}
 #pragma unroll
@@ -81,12 +87,29 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 				if (lane == 0) w.dec[(size_t)b * g.N + nvar[d]] = dec;
 				if (w.post) w.post[((size_t)b * g.N + nvar[d]) * Q + lane] = post[0];
 			}
-			double nv[1] = {post[0] - (ownA[d] ? ca[d] : cb[d])};
-			const double old[1] = {ov[d]};
-			if (wave_decide<1>(old, lane, Q) != wave_decide<1>(nv, lane, Q))
-				nv[0] = __dadd_rn(__dmul_rn(r.damp_old, old[0]), __dmul_rn(r.damp_new, nv[0]));
-			vin[d] = lane == 0 ? 0.0 : nv[0];
-			V[(size_t)eidx[d] * Q + lane] = vin[d];
+			double nv = lane == 0 ? 0.0 : post[0] - (ownA[d] ? ca[d] : cb[d]);
+			// DecideLLRVector of the new vector (:1542-1562): lowest symbol among the maxima of {0, nv[1..]}
+			double mx = wave_fmax(nv);
+			uint64_t hit = __ballot(nv == mx);
+			int arg = hit ? __builtin_ctzll(hit) : 0;
+			int bef = uniform(before[d]);
+			if (first) {
+				const double old[1] = {ov[d]};
+				bef = wave_decide<1>(old, lane, Q);
+			}
+			if (bef != arg) {
+				const double old = first ? ov[d] : V[(size_t)eidx[d] * Q + lane];
+				nv = __dadd_rn(__dmul_rn(r.damp_old, old), __dmul_rn(r.damp_new, nv));
+				if (lane == 0) nv = 0.0;
+				mx = wave_fmax(nv);
+				hit = __ballot(nv == mx);
+				arg = hit ? __builtin_ctzll(hit) : 0;
+			}
+			vin[d] = nv;
+			vmax[d] = mx;
+			varg[d] = arg;
+			V[(size_t)eidx[d] * Q + lane] = nv;
+			if (lane == 0) w.edge_dec[(size_t)b * g.E + eidx[d]] = arg;
 		}
 	}
 
@@ -97,9 +120,14 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 		const double v = FUSED ? vin[d] : (lane > 0 ? V[(size_t)g.c_epos[c0 + d] * Q + lane] : 0.0);
 		// most reliable symbol: strict '>' over ascending symbols from a running maximum of 0 (:1798-1807) = the lowest symbol
 		// that holds the maximum of {0, v[1..]}; symbol 0 (value 0) when nothing is positive
-		const double mx = wave_fmax(v);
-		const uint64_t top = __ballot(v == mx);
-		const int arg = top ? __builtin_ctzll(top) : 0;
+		double mx;
+		int arg;
+		if (FUSED) { mx = vmax[d]; arg = varg[d]; } // found by the variable-node stage above
+		else {
+			mx = wave_fmax(v);
+			const uint64_t top = __ballot(v == mx);
+			arg = top ? __builtin_ctzll(top) : 0;
+		}
 		GfMul<Q> mh;
 		mh.init(g.c_h[c0 + d], g.poly, lane);
 		int bd = 0;

@@ -33,6 +33,7 @@ struct NblWork {
 	const double *c2v_prev;         // fused EMS iteration: c2v of the previous iteration (read), c2v = this iteration (written)
 	int store_v2c;                  // fused EMS iteration: also write v2c (state read-back only)
 	int *dec, *out, *iters;
+	int *edge_dec;                  // fused damped iterations (T-EMS, BP): hard decision of every v2c vector of the previous iteration
 	uint8_t *done;
 	int *n_done;                    // device counter of converged codewords
 	unsigned long long *stamps;     // [16] debug: per-section cycle sums of the check-node kernel (NULL = off)
