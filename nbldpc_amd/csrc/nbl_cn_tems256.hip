@@ -8,9 +8,9 @@
 //     dynamic-programme state of those four check sums live in registers;
 //   * layer 1 is a per-lane minimum (layer 0 is the constant {0 at check sum 0}); layers 2 and 3 gather the 24-byte predecessor
 //     record S[s ^ q] from LDS: for the lane's four symbols that is one address (lane ^ q) XOR-ed with the four plane offsets;
-//   * LDS per wave: the trellis (8 KB, needed again by the output stage), the predecessor records (8 KB, later the four
-//     output vectors) and ONE column's candidate list (4 KB) -- 20 KB against 51 KB of the general kernel, which runs less
-//     than one wave per SIMD at q = 256.
+//   * LDS per wave: one 12.2 KB region used in phases (trellis while it is built and again in the output stage, predecessor
+//     records + ONE column's candidate list during the programme, two output vectors at a time) against 51 KB of the general
+//     kernel, which runs less than one wave per SIMD at q = 256.
 // FUSED = true additionally runs the variable-node pass of the iteration for the four incoming edges (dv = 2 codes), exactly
 // as nbl_cn_tems64.hip does.
 #include <hip/hip_runtime.h>
@@ -43,12 +43,16 @@ __device__ __forceinline__ double pick(const double (&u)[DC], int k)
 template <bool FUSED, int NC>
 __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
-	__shared__ double dU[DC][Q];                                  // delta-domain trellis (:1814-1834)
-	__shared__ __attribute__((aligned(16))) char Sraw[2 * Q * 16]; // predecessor records, then the four output vectors
-	__shared__ __attribute__((aligned(16))) Cand cl[Q + 4];       // deviation candidates of the current column
-	double2 *Sv = (double2 *)Sraw;            // [Q] cost of layers 1, 2 of every check sum before the current column
-	uint4 *Sc = (uint4 *)(Sraw + Q * 16);     // [Q] their path codes (x, y)
-	double (*Lc)[Q] = (double (*)[Q])Sraw;    // [DC][Q] extrinsic minima of every output edge (:1075-1102), after the programme
+	// One 12.2 KB region, used in two phases (three waves per SIMD instead of the 1.75 that 20 KB would allow):
+	//   programme:  predecessor records Sv | Sc (8 KB) + the candidate list of the current column (4.1 KB)
+	//   before / after it:  the trellis dU (8 KB, rebuilt from registers for the output stage) + two output vectors Lc (4 KB)
+	__shared__ __attribute__((aligned(16))) char lds[2 * Q * 16 + (Q + 4) * 16];
+	char *Sraw = lds;                                      // predecessor records
+	double2 *Sv = (double2 *)Sraw;                         // [Q] cost of layers 1, 2 of every check sum before the current column
+	uint4 *Sc = (uint4 *)(Sraw + Q * 16);                  // [Q] their path codes (x, y)
+	Cand *cl = (Cand *)(lds + 2 * Q * 16);                 // [Q + 4] deviation candidates of the current column
+	double (*dU)[Q] = (double (*)[Q])lds;                  // [DC][Q] delta-domain trellis (:1814-1834)
+	double (*Lc)[Q] = (double (*)[Q])(lds + DC * Q * 8);   // [2][Q] extrinsic minima of two output edges at a time (:1075-1102)
 
 	const int lane = lane_id();
 	const int b = blockIdx.x / g.M, m = blockIdx.x % g.M;
@@ -128,6 +132,7 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 	for (int d = 0; d < DC; d++)
 #pragma unroll
 		for (int i = 0; i < NS; i++) u[i][d] = dU[d][lane + 64 * i];
+	__syncthreads(); // the region is about to hold the predecessor records
 
 	// ---- 2. stable ascending order of the four columns per symbol, the nr smallest marked (:1836-1890) --------------------
 	int mask[NS], o0[NS], o1[NS];
@@ -229,41 +234,49 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 		if (nc >= 3 && (st[i].v3 < dW[i] || (st[i].v3 == dW[i] && st[i].c3 < eta[i]))) { dW[i] = st[i].v3; eta[i] = st[i].c3; }
 	}
 
-	// ---- 4. outputs of the four edges (Lc overlays the predecessor records: the last barrier above has passed) -------------
+	// ---- 4. outputs, two edges at a time (the trellis goes back into the region: the last barrier above has passed) ---------
 #pragma unroll
 	for (int d = 0; d < DC; d++)
 #pragma unroll
-		for (int i = 0; i < NS; i++) Lc[d][lane + 64 * i] = NBL_DBL_MAX;
-	__syncthreads();
+		for (int i = 0; i < NS; i++) dU[d][lane + 64 * i] = u[i][d];
 #pragma unroll
-	for (int d = 0; d < DC; d++)
+	for (int h = 0; h < DC; h += 2) {
 #pragma unroll
-		for (int i = 0; i < NS; i++) {
-			const int s = lane + 64 * i;
-			const int dev = (int)((eta[i] >> (P * (DC - 1 - d))) & (Q - 1));
-			const double cand = dW[i] - dU[d][dev]; // :1088
-			__hip_atomic_fetch_min(&Lc[d][s ^ dev], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		for (int d = h; d < h + 2; d++)
+#pragma unroll
+			for (int i = 0; i < NS; i++) Lc[d - h][lane + 64 * i] = NBL_DBL_MAX;
+		__syncthreads();
+#pragma unroll
+		for (int d = h; d < h + 2; d++)
+#pragma unroll
+			for (int i = 0; i < NS; i++) {
+				const int s = lane + 64 * i;
+				const int dev = (int)((eta[i] >> (P * (DC - 1 - d))) & (Q - 1));
+				const double cand = dW[i] - dU[d][dev]; // :1088
+				__hip_atomic_fetch_min(&Lc[d - h][s ^ dev], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		__syncthreads();
+#pragma unroll
+		for (int d = h; d < h + 2; d++)
+#pragma unroll
+			for (int i = 0; i < NS; i++) {
+				const int s = lane + 64 * i;
+				if (Lc[d - h][s] == NBL_DBL_MAX) Lc[d - h][s] = (d == o0[i]) ? pick(u[i], o1[i]) : pick(u[i], o0[i]); // never reached (:1095-1102)
+			}
+		__syncthreads();
+#pragma unroll
+		for (int d = h; d < h + 2; d++) {
+			// delta domain -> LLR, un-permute by h (:1105-1127)
+			const int bsyn = syn ^ beta[d];
+			const double L0 = -1.0 * Lc[d - h][bsyn];
+#pragma unroll
+			for (int i = 0; i < NS; i++) {
+				const int a = lane + 64 * i;
+				const int e = mh[d].at_slot(i) ^ bsyn; // eta with h^-1 (eta ^ bsyn) = a
+				C[(size_t)d * Q + a] = (a == 0) ? 0.0 : shape_llr(-1.0 * Lc[d - h][e] - L0, r.factor, r.offset);
+			}
 		}
-	__syncthreads();
-#pragma unroll
-	for (int d = 0; d < DC; d++)
-#pragma unroll
-		for (int i = 0; i < NS; i++) {
-			const int s = lane + 64 * i;
-			if (Lc[d][s] == NBL_DBL_MAX) Lc[d][s] = (d == o0[i]) ? pick(u[i], o1[i]) : pick(u[i], o0[i]); // never reached (:1095-1102)
-		}
-	__syncthreads();
-#pragma unroll
-	for (int d = 0; d < DC; d++) {
-		// delta domain -> LLR, un-permute by h (:1105-1127)
-		const int bsyn = syn ^ beta[d];
-		const double L0 = -1.0 * Lc[d][bsyn];
-#pragma unroll
-		for (int i = 0; i < NS; i++) {
-			const int a = lane + 64 * i;
-			const int e = mh[d].at_slot(i) ^ bsyn; // eta with h^-1 (eta ^ bsyn) = a
-			C[(size_t)d * Q + a] = (a == 0) ? 0.0 : shape_llr(-1.0 * Lc[d][e] - L0, r.factor, r.offset);
-		}
+		__syncthreads(); // Lc is reused by the next pair of edges
 	}
 }
 
