@@ -13,7 +13,8 @@ public:
 	std::vector<int> devices;
 	std::vector<std::unique_ptr<CComm>> lanes;
 	std::vector<double> L_batch[2];    // [parallel][N][q-1], one buffer per cycle in flight
-	bool device_demod = false;         // NBL_DEVICE_DEMOD=1: ship received samples, demodulate on the GPU
+	bool device_demod = true;          // ship received samples, demodulate on the GPU (bit-identical L_ch);
+	                                   // NBL_DEVICE_DEMOD=0: build L_ch on the host as the reference's Demodulate does
 	std::vector<double> rx_batch[2];   // [parallel][MOD_SYM_LEN][2]
 	bool pipeline = true;              // NBL_PIPELINE=0: strictly serial cycles
 	int host_threads = 1;

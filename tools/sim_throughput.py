@@ -3,7 +3,7 @@
 
 usage: python tools/sim_throughput.py [cfg3|cfg2|cfg4] [parallel] [cycles] [ebn0]
 Runs the driver in a scratch directory for `cycles` simulation cycles (stop rule on the frame count only), prints its phase summary.
-NBL_DEVICE_DEMOD=1 ships received samples instead of symbol LLRs; NBL_HOST_THREADS sets the front-end threads.
+NBL_DEVICE_DEMOD=0 builds the symbol LLRs on the host instead of shipping received samples; NBL_HOST_THREADS sets the front-end threads.
 """
 import os
 import subprocess
