@@ -5,6 +5,8 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <map>
+#include <mutex>
 #include <vector>
 
 // seed + lane for the three generators, PN register pre-advanced lane steps (Comm.cpp:58-74, :160-173)
@@ -13,8 +15,10 @@ void CComm::ResetSources(CSimulation &sim, int lane)
 	Rand.IX = Rand.IY = Rand.IZ = sim.randomseed;
 	if (lane) { Rand.IX += lane; Rand.IY += lane; Rand.IZ += lane; }
 	static const int init[11] = {1, 0, 1, 0, 0, 0, 1, 1, 0, 0, 1};
-	memcpy(regPN, init, sizeof init);
+	pn = 0;
+	for (int i = 0; i < 11; i++) pn |= init[i] << i;
 	SkipPN(lane);
+	pn_jump = PnJumpTable(sim.parallel - 1);
 }
 
 bool CComm::Initial(CSimulation &sim, int lane, CNBLDPC *shared)
@@ -130,21 +134,24 @@ void CComm::DemodSource(std::vector<int> &src) const
 // 11-stage shift register, output r10, feedback r10 ^ r3 after the shift (Comm.cpp:241-252)
 int CComm::GenPN()
 {
-	for (int i = 10; i >= 1; i--) regPN[i] = regPN[i - 1];
-	regPN[0] = regPN[10] ^ regPN[3];
-	return regPN[10];
+	const int out = (pn >> 9) & 1, fb = ((pn >> 9) ^ (pn >> 2)) & 1; // shift, then regPN[0] = regPN[10] ^ regPN[3]; output regPN[10]
+	pn = ((pn << 1) & 2047) | fb;
+	return out;
 }
 
 // The register update is a linear map of an 11-bit state, so "clock it n times" is a table walk: the map is squared
-// repeatedly (2048-entry tables) and the tables of the set bits of n are applied.  Same register contents as n calls of
-// GenPN(); the reference clocks one by one (Comm.cpp:201), which is O(parallel) per message bit.
+// repeatedly (2048-entry tables) and the tables of the set bits of n are applied; for the one n the message generator needs
+// (parallel - 1, Comm.cpp:201) the walk is folded into a single table once.  Same register contents as n calls of GenPN();
+// the reference clocks one by one, which is O(parallel) per message bit.
 namespace {
 struct PnTables {
 	std::vector<std::vector<unsigned short>> pow2; // pow2[k][state] = state after 2^k clocks
+	std::map<int, std::vector<unsigned short>> jumps;
+	std::mutex mu;
 	PnTables()
 	{
 		std::vector<unsigned short> t(2048);
-		for (int s = 0; s < 2048; s++) { // bit i of s = regPN[i]
+		for (int s = 0; s < 2048; s++) {
 			const int fb = ((s >> 9) ^ (s >> 2)) & 1; // the feedback is taken after the shift (Comm.cpp:246-250)
 			t[s] = (unsigned short)(((s << 1) & 2047) | fb);
 		}
@@ -155,23 +162,36 @@ struct PnTables {
 			pow2.push_back(n);
 		}
 	}
+	int walk(int s, int n) const
+	{
+		for (int k = 0; k < 31; k++)
+			if ((n >> k) & 1) s = pow2[k][s];
+		return s;
+	}
 };
-const PnTables &pn_tables()
+PnTables &pn_tables()
 {
-	static const PnTables t;
+	static PnTables t;
 	return t;
 }
 } // namespace
 
 void CComm::SkipPN(int n)
 {
-	if (n <= 0) return;
-	const PnTables &t = pn_tables();
-	int s = 0;
-	for (int i = 0; i < 11; i++) s |= regPN[i] << i;
-	for (int k = 0; k < 31; k++)
-		if ((n >> k) & 1) s = t.pow2[k][s];
-	for (int i = 0; i < 11; i++) regPN[i] = (s >> i) & 1;
+	if (n > 0) pn = pn_tables().walk(pn, n);
+}
+
+const unsigned short *CComm::PnJumpTable(int n)
+{
+	PnTables &t = pn_tables();
+	std::lock_guard<std::mutex> lock(t.mu);
+	auto it = t.jumps.find(n);
+	if (it == t.jumps.end()) {
+		std::vector<unsigned short> j(2048);
+		for (int s = 0; s < 2048; s++) j[s] = (unsigned short)(n > 0 ? t.walk(s, n) : s);
+		it = t.jumps.emplace(n, std::move(j)).first;
+	}
+	return it->second.data();
 }
 
 // every lane draws from the SAME PN sequence, interleaved: lane i uses outputs i, i+P, i+2P, .. (Comm.cpp:199-202)
@@ -180,7 +200,7 @@ int CComm::GenerateMessage()
 	const int nb = MSG_BIT_LEN - crcLen;
 	for (int b = 0; b < nb; b++) {
 		if (randomMsg) {
-			SkipPN(parallel_num - 1);
+			pn = pn_jump[pn]; // parallel - 1 clocks
 			TX_MSG_BIT_beforeCRC[b] = GenPN();
 		} else {
 			TX_MSG_BIT_beforeCRC[b] = 0;

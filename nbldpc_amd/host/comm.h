@@ -17,7 +17,8 @@ public:
 	int GFq = 0, parallel_num = 1, Bit_Len_PerSYM = 0;
 	CNBLDPC *NBLDPC = nullptr;
 	CRand Rand;
-	int regPN[11] = {0};
+	int pn = 0;                        // the 11-stage PN register, bit i = regPN[i] of the reference (Comm.h)
+	const unsigned short *pn_jump = nullptr; // state after `parallel - 1` clocks, per state (one look-up per message bit)
 	int randomMsg = 0, crcLen = 0, crcLen_correct = 0;
 	int MSG_SYM_LEN = 0, MSG_BIT_LEN = 0, CODE_SYM_LEN = 0, CODE_BIT_LEN = 0, PUN_SYM_LEN = 0, PUN_BIT_LEN = 0;
 	int modOrder = 0, MOD_BIT_PER_SYM = 0, MOD_SYM_LEN = 0, MOD_BIT_LEN = 0;
@@ -57,4 +58,5 @@ public:
 private:
 	void ResetSources(CSimulation &sim, int parallel_order);
 	void SkipPN(int n); // clock the PN register n times (table walk)
+	static const unsigned short *PnJumpTable(int n); // state -> state after n clocks (cached per n)
 };
