@@ -9,8 +9,8 @@
 //   * every vector is held as probabilities relative to its own maximum, mantissa in [1,2] x 2^e with a separate 32-bit
 //     exponent, IN REGISTERS (12 VGPRs per vector); LDS holds only the two operands of the running convolution (6 KB per wave,
 //     the generic kernel needs 35 KB and runs one wave per SIMD);
-//   * narrow convolutions (the smaller of the two input ranges below 650 nats: every output then has a term >= e^-650, so
-//     whatever underflows is below 2^-76 of the result) run on plain doubles, one FMA per term;
+//   * narrow convolutions (the smaller of the two input ranges below 1000 nats; both operands pre-scaled by 2^500, see lse_conv)
+//     run on plain doubles, one FMA per term;
 //   * wide convolutions (LLRs thousands of nats apart, the normal state after a few iterations of a converged frame) take
 //     the per-output top exponent first (integer max-plus pass), then one v_add3 + v_ldexp_f64 + v_fma_f64 per term: every
 //     term is scaled exactly, nothing is lost to underflow -- the reference's log-domain recursion has unlimited range and
@@ -75,13 +75,18 @@ struct Lds {
 // out[z] = LSE_x(A[x] + B[z^x]) - LSE_x(A[x] + B[x]) for the lane's symbols z = 4 lane + i (log domain, out[0] = 0)
 __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&out)[4], const Lds &s, int lane)
 {
-	const bool narrow = fmin(A.rng, B.rng) < 650.0; // wave-uniform
+	// Both operands are scaled by 2^500 for the plain-double path: an entry then survives down to e^-1054 of its vector's maximum
+	// and a product down to e^-1400 of the largest product.  Every output has a term >= e^-min(range) (the maximum of one vector
+	// times any entry of the other), and a term within e^-40 of it has both factors within e^-(min(range)+40) of their maxima:
+	// with min(range) < 1000 nats nothing that matters underflows, and 256 products of at most 2^1000 cannot overflow.
+	constexpr int SH = 500;
+	const bool narrow = fmin(A.rng, B.rng) < 1000.0; // wave-uniform
 	double lse[4];
 	if (narrow) {
-		s.Am01[lane] = make_double2(ldexp(A.m[0], A.e[0]), ldexp(A.m[1], A.e[1]));
-		s.Am23[lane] = make_double2(ldexp(A.m[2], A.e[2]), ldexp(A.m[3], A.e[3]));
-		s.Bm01[lane] = make_double2(ldexp(B.m[0], B.e[0]), ldexp(B.m[1], B.e[1]));
-		s.Bm23[lane] = make_double2(ldexp(B.m[2], B.e[2]), ldexp(B.m[3], B.e[3]));
+		s.Am01[lane] = make_double2(ldexp(A.m[0], A.e[0] + SH), ldexp(A.m[1], A.e[1] + SH));
+		s.Am23[lane] = make_double2(ldexp(A.m[2], A.e[2] + SH), ldexp(A.m[3], A.e[3] + SH));
+		s.Bm01[lane] = make_double2(ldexp(B.m[0], B.e[0] + SH), ldexp(B.m[1], B.e[1] + SH));
+		s.Bm23[lane] = make_double2(ldexp(B.m[2], B.e[2] + SH), ldexp(B.m[3], B.e[3] + SH));
 		__syncthreads();
 		double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 2
@@ -95,7 +100,7 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 				for (int i = 0; i < 4; i++) acc[i] = __fma_rn(a[j], b[i ^ j], acc[i]);
 		}
 #pragma unroll
-		for (int i = 0; i < 4; i++) lse[i] = (log(acc[i]) + A.mx) + B.mx;
+		for (int i = 0; i < 4; i++) lse[i] = ((log(acc[i]) - (2 * SH) * LN2) + A.mx) + B.mx;
 	} else {
 		s.Am01[lane] = make_double2(A.m[0], A.m[1]);
 		s.Am23[lane] = make_double2(A.m[2], A.m[3]);
