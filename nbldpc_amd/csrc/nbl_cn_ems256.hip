@@ -450,10 +450,15 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		for (int x = 0; x < 4; x++) {
 			if (x == j) continue;
 			const int shift = ztot ^ ztop[x] ^ ztop[j];
+			// U[s ^ shift] for the lane's four symbols: two 16-byte reads (the XOR permutes 16-byte slots; bit 0 swaps inside a slot)
+			const int ad = (lane << 4) ^ ((shift & 0xFE) << 3);
+			const double2 ra = *(const double2 *)((const char *)U + ad), rb = *(const double2 *)((const char *)U + (ad ^ 1024));
+			const bool sw = shift & 1;
+			const double uu[4] = {sw ? ra.y : ra.x, sw ? ra.x : ra.y, sw ? rb.y : rb.x, sw ? rb.x : rb.y};
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
 				double acc = 0.0;
-				const double u = U[sym_of(lane, i) ^ shift];
+				const double u = uu[i];
 #pragma unroll
 				for (int o = 0; o < 4; o++) {
 					if (o == x) continue;
