@@ -25,7 +25,6 @@ namespace {
 constexpr int Q = 256;
 
 struct __attribute__((aligned(16))) ListEnt { double v; int t; int tt; };   // tt = (t & 0xFE) << 3: byte offset XOR of the gather
-struct __attribute__((aligned(16))) CandEnt { double v; int a; int pad; };
 
 // ---- 64-bit wave max through DPP moves (no LDS) ------------------------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xF>
