@@ -232,6 +232,20 @@ extern "C" nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_m
 	for (int m = 0; m < M; m++) d->all_dc4 = d->all_dc4 && (code->chk_deg[m] == 4);
 	d->all_dv2 = true;
 	for (int n = 0; n < N; n++) d->all_dv2 = d->all_dv2 && (code->var_deg[n] == 2);
+	if (q == 256 && d->all_dc4) {
+		// permutation offsets of the specialised EMS kernel: variable-domain symbol a of lane l -> byte offset of h*a in a q-vector
+		std::vector<unsigned long long> toff((size_t)E * 64);
+		for (int ce = 0; ce < E; ce++)
+			for (int l = 0; l < 64; l++) {
+				unsigned long long pk = 0;
+				for (int i = 0; i < 4; i++) {
+					const int a = 2 * l + (i & 1) + 128 * (i >> 1);
+					pk |= (unsigned long long)(8u * gf_mul[(size_t)c_h[ce] * q + a]) << (16 * i);
+				}
+				toff[(size_t)ce * 64 + l] = pk;
+			}
+		if ((st = upload(d, toff, &d->g.ems_toff))) return fail_create(d, st, "");
+	}
 	void *cnt = nullptr;
 	if (hipMalloc(&cnt, 16) != hipSuccess) return fail_create(d, NBL_ERR_NOMEM, "hipMalloc failed");
 	d->graph_allocs.push_back(cnt);

@@ -7,14 +7,21 @@
 //   * lane l owns symbols {2l, 2l+1, 128+2l, 129+2l}: a q-vector is two 16-byte loads/stores per lane, and a
 //     max-plus XOR-gather "P[s ^ t]" is two conflict-free ds_read_b128 (natural layout, lane XOR only permutes the
 //     16-byte slots inside one 256-byte LDS row).
-//   * the four conf(q,1) result vectors stay in registers; 2 KB LDS buffers U (also histogram / S staging) and P plus
-//     the packed lists -> 7 KB per wave at nm = 32, four waves per SIMD (VGPR-limited).
-//   * the nm-best lists are packed {value, symbol} 16-byte entries, split by bit 0 of the symbol so the pair swap
-//     of the gather is resolved by loop structure instead of per-element selects.
+//   * the incoming vectors arrive in the variable domain (symbol a) and are moved ONCE into the check domain (t = h a)
+//     through LDS -- the staging conf(q,1) needs anyway; everything after that (top-nm selection, list building, the
+//     convolutions) works on check-domain registers, where the lane's symbols are the same for all four edges: slot
+//     parity is a compile-time property, list entries need no per-element symbol arithmetic.  The byte offsets 8 h a
+//     of the permutation come from a per-edge table built by nbl_create (g.ems_toff), not from GF arithmetic.
 //   * top-nm selection without sorting: a 256-bucket histogram (LDS atomics + DPP prefix sum) finds the bucket that
 //     holds the nm-th best value; if that bucket ends exactly at the nm-th entry the members are known, otherwise a ballot
 //     quickselect inside the bucket finds the exact cut under SortLLRVector's order (value desc, higher symbol first
 //     among equals).
+//   * wave maxima / minima are reduced on order-preserving 32-bit keys (one DPP instruction per step); the lane that holds
+//     the maximum key delivers the exact FP64 value.
+//   * conf(nm, nc >= 3): the three pair convolutions e0(+)e1, e0(+)e2, e1(+)e2 are scattered in one pass into three LDS
+//     buffers; the outputs 2, 1, 0 all gather over the list of edge 3 and share one loop (one broadcast read of the list
+//     entry and one address per entry serve three convolutions).
+//   * 8 KB LDS per wave at nm = 32 (three q-vectors + the lists), four waves per SIMD (VGPR-limited).
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "nbl_device.h"
@@ -26,7 +33,11 @@ constexpr int Q = 256;
 
 struct __attribute__((aligned(16))) ListEnt { double v; int t; int tt; };   // tt = (t & 0xFE) << 3: byte offset XOR of the gather
 
-// ---- 64-bit wave max through DPP moves (no LDS) ------------------------------------------------------------------
+// One wave per workgroup: LDS operations of one wave execute in issue order, so phases that hand data over through LDS only
+// need the COMPILER to keep the order -- no s_barrier, no drain of the LDS queue.
+#define WSYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+
+// ---- 64-bit wave max through DPP moves (no LDS); used only where the 32-bit key reduction is ambiguous ---------
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ double dpp_mov_f64(double x)
 {
@@ -46,17 +57,6 @@ __device__ __forceinline__ double wave_max_f64(double x)
 	return read_lane_f64(x, 63);
 }
 
-__device__ __forceinline__ double wave_min_f64(double x)
-{
-	x = dmin(x, dpp_mov_f64<0xB1>(x));
-	x = dmin(x, dpp_mov_f64<0x4E>(x));
-	x = dmin(x, dpp_mov_f64<0x141>(x));
-	x = dmin(x, dpp_mov_f64<0x140>(x));
-	x = dmin(x, dpp_mov_f64<0x142, 0xA>(x));
-	x = dmin(x, dpp_mov_f64<0x143, 0xC>(x));
-	return read_lane_f64(x, 63);
-}
-
 // inclusive prefix sum over the 64 lanes (the DPP sequence LLVM's atomic optimiser emits on gfx9)
 __device__ __forceinline__ int wave_scan_add(int x)
 {
@@ -69,16 +69,48 @@ __device__ __forceinline__ int wave_scan_add(int x)
 	return x;
 }
 
+// wave max / min of 32-bit integers: with the operation's identity as the DPP `old` value hipcc folds the move into the
+// v_max_i32_dpp / v_min_i32_dpp itself (six instructions per reduction)
 __device__ __forceinline__ int wave_max_i32(int x)
 {
+	constexpr int ID = (int)0x80000000;
 	auto mx = [](int a, int b) { return a > b ? a : b; };
-	x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));
-	x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));
-	x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));
-	x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false));
-	x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xA, 0xF, false));
-	x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xC, 0xF, false));
+	x = mx(x, __builtin_amdgcn_update_dpp(ID, x, 0xB1, 0xF, 0xF, false));
+	x = mx(x, __builtin_amdgcn_update_dpp(ID, x, 0x4E, 0xF, 0xF, false));
+	x = mx(x, __builtin_amdgcn_update_dpp(ID, x, 0x141, 0xF, 0xF, false));
+	x = mx(x, __builtin_amdgcn_update_dpp(ID, x, 0x140, 0xF, 0xF, false));
+	x = mx(x, __builtin_amdgcn_update_dpp(ID, x, 0x142, 0xA, 0xF, false));
+	x = mx(x, __builtin_amdgcn_update_dpp(ID, x, 0x143, 0xC, 0xF, false));
 	return __builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ int wave_min_i32(int x)
+{
+	constexpr int ID = 0x7fffffff;
+	auto mn = [](int a, int b) { return a < b ? a : b; };
+	x = mn(x, __builtin_amdgcn_update_dpp(ID, x, 0xB1, 0xF, 0xF, false));
+	x = mn(x, __builtin_amdgcn_update_dpp(ID, x, 0x4E, 0xF, 0xF, false));
+	x = mn(x, __builtin_amdgcn_update_dpp(ID, x, 0x141, 0xF, 0xF, false));
+	x = mn(x, __builtin_amdgcn_update_dpp(ID, x, 0x140, 0xF, 0xF, false));
+	x = mn(x, __builtin_amdgcn_update_dpp(ID, x, 0x142, 0xA, 0xF, false));
+	x = mn(x, __builtin_amdgcn_update_dpp(ID, x, 0x143, 0xC, 0xF, false));
+	return __builtin_amdgcn_readlane(x, 63);
+}
+
+// order-preserving 32-bit key of a double: round to float (monotone), then sign-magnitude -> two's complement
+__device__ __forceinline__ int key32(double x)
+{
+	const int b = __float_as_int((float)x);
+	return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float unkey32(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+
+// exact wave maximum of `loc` given the wave maximum `kmax` of its keys: rounding is monotone, so the maximum sits in a
+// lane whose key equals kmax; one such lane (the rule) -> read it, several -> full FP64 reduction
+__device__ __forceinline__ double wave_max_exact(double loc, int key, int kmax)
+{
+	const uint64_t c = __ballot(key == kmax);
+	if (__builtin_popcountll(c) == 1) return read_lane_f64(loc, __builtin_ctzll(c));
+	return wave_max_f64(loc);
 }
 
 // symbol of slot i of lane l in this kernel's layout
@@ -98,8 +130,23 @@ __device__ __forceinline__ int highest_sym(const uint64_t (&m)[4])
 	}
 	return best;
 }
+// lowest symbol among the set bits of four slot masks (Q if empty)
+__device__ __forceinline__ int lowest_sym(const uint64_t (&m)[4])
+{
+	int best = Q;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		if (m[i]) {
+			int l = __builtin_ctzll(m[i]);
+			int a = 2 * l + (i & 1) + 128 * (i >> 1);
+			best = a < best ? a : best;
+		}
+	}
+	return best;
+}
 
 // h * a for this layout: lane bits 0..5 are symbol bits 1..6, slot bit 0 is symbol bit 0, slot bit 1 is symbol bit 7
+// (only the rare tie path of the selection uses it; the permutation offsets of the main path come from g.ems_toff)
 struct GfMulL {
 	int b0, b7, lane_part;
 	__device__ __forceinline__ void init(int h, int poly, int lane)
@@ -116,17 +163,6 @@ struct GfMulL {
 		}
 	}
 	__device__ __forceinline__ int at_slot(int i) const { return lane_part ^ ((i & 1) ? b0 : 0) ^ ((i & 2) ? b7 : 0); }
-	__device__ __forceinline__ int scalar(int a, int h, int poly) const
-	{
-		int x = h, acc = 0;
-#pragma unroll
-		for (int i = 0; i < 8; i++) {
-			if ((a >> i) & 1) acc ^= x;
-			x <<= 1;
-			if (x & Q) x ^= poly;
-		}
-		return acc;
-	}
 };
 
 struct SelState {
@@ -166,28 +202,43 @@ __device__ __forceinline__ void select_step(const double (&v)[4], int nm, SelSta
 	}
 }
 
-// members of the nm best under SortLLRVector's order (value desc, higher symbol first among equals, NBLDPC.cpp:1731)
-__device__ __forceinline__ void finish_members(SelState &s, int nm, uint64_t (&member)[4])
+// members of the nm best under SortLLRVector's order (value desc, higher symbol first among equals, NBLDPC.cpp:1731).
+// The masks are over CHECK-domain slots; the tie rule is about the variable-domain symbol a = hinv * t.
+__device__ __forceinline__ void finish_ties(uint64_t (&member)[4], const uint64_t (&eqin)[4], int need, int hinv, int poly, int lane)
+{
+	GfMulL mh;
+	mh.init(hinv, poly, lane);
+	uint64_t eq[4] = {eqin[0], eqin[1], eqin[2], eqin[3]};
+	for (; need > 0; need--) {
+		int best = -1;
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int a = __builtin_amdgcn_inverse_ballot_w64(eq[i]) ? mh.at_slot(i) : -1;
+			best = a > best ? a : best;
+		}
+		const int amax = wave_max_i32(best);
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const uint64_t hit = __ballot(__builtin_amdgcn_inverse_ballot_w64(eq[i]) && mh.at_slot(i) == amax);
+			member[i] |= hit;
+			eq[i] &= ~hit;
+		}
+	}
+}
+
+__device__ __forceinline__ void finish_members(SelState &s, int nm, uint64_t (&member)[4], int hinv, int poly, int lane)
 {
 	int cgt = 0, ceq = 0;
 #pragma unroll
 	for (int i = 0; i < 4; i++) { cgt += __popcll(s.gt[i]); ceq += __popcll(s.eq[i]); }
-	int need = nm - cgt;
+	const int need = nm - cgt;
 #pragma unroll
 	for (int i = 0; i < 4; i++) member[i] = s.gt[i];
 	if (need == ceq) {
 #pragma unroll
 		for (int i = 0; i < 4; i++) member[i] |= s.eq[i];
 	} else {
-		// ties straddle the cut: take the highest symbols of the tie group (rare)
-		uint64_t eq[4] = {s.eq[0], s.eq[1], s.eq[2], s.eq[3]};
-		for (; need > 0; need--) {
-			int a = highest_sym(eq);
-			int i = ((a >> 7) << 1) | (a & 1), l = (a & 127) >> 1;
-#pragma unroll
-			for (int k = 0; k < 4; k++)
-				if (k == i) { member[k] |= 1ull << l; eq[k] &= ~(1ull << l); }
-		}
+		finish_ties(member, s.eq, need, hinv, poly, lane); // ties straddle the cut: the highest symbols of the tie group (rare)
 	}
 }
 
@@ -203,10 +254,9 @@ template <int NM, bool FUSED, int NC>
 __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	constexpr int LOGNM = (NM == 8) ? 3 : (NM == 16) ? 4 : 5;
-	constexpr int NMP = NM; // list stride per edge: [even-symbol group | odd-symbol group], back to back
 	// static LDS: its base is a compile-time constant, so computed addresses fold into the ds_* offset fields (with `extern
 	// __shared__` every computed address pays a v_add with the link-time base)
-	__shared__ __attribute__((aligned(16))) char smem[2 * Q * 8 + Q / 2 * 8 + 4 * NM * 16];
+	__shared__ __attribute__((aligned(16))) char smem[3 * Q * 8 + 4 * NM * 16];
 	const int lane = lane_id();
 	// XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  All checks of
 	// a codeword are given to ONE XCD, so the second read of every L_ch / c2v vector (each is used by two checks) can hit
@@ -217,12 +267,11 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m];
 
-	double *U = (double *)smem;              // [256] check-domain copy of one input vector | histogram | S of one output
-	double *P = U + Q;                       // [256] pair convolution (U..P together: candidate buffer of the selection)
-	// P[256..383] mirrors P[0..127] while a gather runs: the partner half of chunk `ad` is then always at ad + 1024
-	ListEnt *lstp = (ListEnt *)(P + Q + Q / 2); // [4][NM]  the nm best of every edge, grouped by symbol bit 0
+	// three q-vectors: staging of the incoming vectors | histogram (B0..B1) | the three pair convolutions | staging of the outputs
+	double *const B0 = (double *)smem, *const B1 = B0 + Q, *const B2 = B1 + Q;
+	ListEnt *const lstp = (ListEnt *)(B2 + Q); // [4][NM]  the nm best of every edge: [even-symbol group | odd-symbol group]
 
-	// per-section cycle stamps (tools/stamps.py): compiled in only with -DNBL_EMS_STAMPS -- the thirteen 64-bit accumulators
+	// per-section cycle stamps (tools/stamps.py): compiled in only with -DNBL_EMS_STAMPS -- the accumulators
 	// live in SGPRs for the whole kernel and push the selection code into SGPR spills
 #ifdef NBL_EMS_STAMPS
 	unsigned long long st_t0 = 0, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -238,12 +287,14 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	const double *V = w.v2c + (size_t)b * g.E * Q;
 	double *C = w.c2v + ((size_t)b * g.E + c0) * Q;
 
-	// ---- load the four incoming vectors (two 16-byte loads each) and their check-domain symbols ------------------
+	// byte offsets 8 * (h_j * a) of the lane's four variable-domain symbols in a check-domain vector, 16 bits each
+	uint2 toff[4];
+#define TOFF(j, i) ((int)((((i) & 2) ? toff[j].y : toff[j].x) >> (16 * ((i) & 1))) & 0xffff)
+#pragma unroll
+	for (int j = 0; j < 4; j++) toff[j] = ((const uint2 *)g.ems_toff)[(size_t)(c0 + j) * 64 + lane];
+
+	// ---- load the four incoming vectors (two 16-byte loads each) ----------------------------------------------------
 	double v[4][4];
-	unsigned tp[4]; // check-domain symbols h_j * a of the lane's four slots, packed one byte each (keeps 12 VGPRs free:
-	                // with 16 separate registers hipcc rematerialises the GF multiplication at every use)
-#define TSYM(j, i) ((int)((tp[j] >> (8 * (i))) & 255u))
-	int hcoef[4];
 	if (!FUSED) {
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
@@ -253,7 +304,6 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			v[j][1] = d0.y;
 			v[j][2] = d1.x;
 			v[j][3] = d1.y;
-			hcoef[j] = g.c_h[c0 + j];
 		}
 	} else {
 		const double *Cp = w.c2v_prev + (size_t)b * g.E * Q;
@@ -273,7 +323,6 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			b0[j] = pb[lane]; b1[j] = pb[64 + lane];
 			nvar[j] = n; eidx[j] = e;
 			ownA[j] = (e == e0); // this check is the variable's first edge
-			hcoef[j] = g.c_h[c0 + j];
 		}
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
@@ -288,11 +337,13 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			if (ownA[j]) {
 				// hard decision (DecideLLRVector :1542-1562): lowest symbol among the maxima, 0 unless the maximum is positive
 				if (lane == 0) post[0] = 0.0;
-				const double pm = wave_max_f64(dmax(dmax(post[0], post[1]), dmax(post[2], post[3])));
-				int cand = 0x7fffffff;
+				const double locp = dmax(dmax(post[0], post[1]), dmax(post[2], post[3]));
+				const int kp = key32(locp);
+				const double pm = wave_max_exact(locp, kp, wave_max_i32(kp));
+				uint64_t hit[4];
 #pragma unroll
-				for (int i = 3; i >= 0; i--) cand = (post[i] == pm) ? sym_of(lane, i) : cand;
-				const int arg = -wave_max_i32(-cand);
+				for (int i = 0; i < 4; i++) hit[i] = __ballot(post[i] == pm);
+				const int arg = lowest_sym(hit);
 				if (lane == 0) w.dec[(size_t)b * g.N + n] = (pm > 0.0) ? arg : 0;
 				if (w.post) {
 					double2 *pp = (double2 *)(w.post + ((size_t)b * g.N + n) * Q);
@@ -311,12 +362,6 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			}
 		}
 	}
-#pragma unroll
-	for (int j = 0; j < 4; j++) {
-		GfMulL mh;
-		mh.init(hcoef[j], g.poly, lane);
-		tp[j] = (unsigned)mh.at_slot(0) | ((unsigned)mh.at_slot(1) << 8) | ((unsigned)mh.at_slot(2) << 16) | ((unsigned)mh.at_slot(3) << 24);
-	}
 	STAMP(0);
 
 	// ---- rank 0 of every edge: value m_j, check-domain symbol z_j (highest symbol among equal maxima, :1731) -------
@@ -324,31 +369,83 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	int ztop[4];
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
-		double loc = dmax(dmax(v[j][0], v[j][1]), dmax(v[j][2], v[j][3]));
-		mtop[j] = wave_max_f64(loc);
-		lmin[j] = wave_min_f64(loc); // 64 distinct entries are >= lmin, so the nm-th best (nm <= 64) is too
+		const double loc = dmax(dmax(v[j][0], v[j][1]), dmax(v[j][2], v[j][3]));
+		const int k = key32(loc);
+		mtop[j] = wave_max_exact(loc, k, wave_max_i32(k));
+		// 64 distinct entries are >= the smallest lane maximum, so the nm-th best (nm <= 64) is too; the key of that minimum is
+		// taken one float step down (rounding may have gone up) -- any lower bound will do
+		const double lf = dmin((double)unkey32(wave_min_i32(k)), 3.0e38); // (a float infinity must not become the bound)
+		lmin[j] = (lf - __builtin_fabs(lf) * 0x1p-22) - 0x1p-120;
 		uint64_t eqm[4];
 #pragma unroll
 		for (int i = 0; i < 4; i++) eqm[i] = __ballot(v[j][i] == mtop[j]);
-		const int topa = highest_sym(eqm);
-		ztop[j] = g.mul[hcoef[j] * Q + topa];
+		const int topa = highest_sym(eqm); // variable-domain symbol of rank 0
+		const int tl = (topa & 127) >> 1;
+		const unsigned twl = (unsigned)__builtin_amdgcn_readlane((int)toff[j].x, tl), twh = (unsigned)__builtin_amdgcn_readlane((int)toff[j].y, tl);
+		const unsigned tw = (topa & 128) ? twh : twl;
+		ztop[j] = (int)((tw >> (16 * (topa & 1))) & 0xffffu) >> 3;
 	}
 	STAMP(1);
 
-	// ---- top-nm selection -------------------------------------------------------------------------------------------
+	// ---- conf(q,1): one edge deviates to any symbol, the others stay at rank 0 (:894).  The staging of edge j in the check
+	// domain also brings the vector back as check-domain registers: from here on slot i of every edge is symbol sym_of(lane, i)
+	double S[4][4];
+#pragma unroll
+	for (int x = 0; x < 4; x++)
+#pragma unroll
+		for (int i = 0; i < 4; i++) S[x][i] = -NBL_DBL_MAX;
+	const int ztot = ztop[0] ^ ztop[1] ^ ztop[2] ^ ztop[3];
+	const int lane16 = lane << 4;
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		char *const Uj = (char *)(j == 1 ? B1 : j == 2 ? B2 : B0); // B0, B1, B2, B0: no buffer is rewritten while reads of it are in flight
+		WSYNC();
+#pragma unroll
+		for (int i = 0; i < 4; i++) *(double *)(Uj + TOFF(j, i)) = v[j][i];
+		WSYNC();
+#pragma unroll
+		for (int x = 0; x < 4; x++) {
+			if (x == j) continue;
+			const int shift = ztot ^ ztop[x] ^ ztop[j];
+			// U[s ^ shift] for the lane's four symbols: two 16-byte reads (the XOR permutes 16-byte slots; bit 0 swaps inside a slot)
+			const int ad = lane16 ^ ((shift & 0xFE) << 3);
+			const double2 ra = *(const double2 *)(Uj + ad), rb = *(const double2 *)(Uj + (ad ^ 1024));
+			const bool sw = shift & 1;
+			const double uu[4] = {sw ? ra.y : ra.x, sw ? ra.x : ra.y, sw ? rb.y : rb.x, sw ? rb.x : rb.y};
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				double acc = 0.0;
+				const double u = uu[i];
+#pragma unroll
+				for (int o = 0; o < 4; o++) {
+					if (o == x) continue;
+					acc = acc + ((o == j) ? u : mtop[o]);
+				}
+				S[x][i] = dmax(S[x][i], acc);
+			}
+		}
+		if (NC >= 2) {
+			const double2 d0 = *(const double2 *)(Uj + lane16), d1 = *(const double2 *)(Uj + lane16 + 1024);
+			v[j][0] = d0.x; v[j][1] = d0.y; v[j][2] = d1.x; v[j][3] = d1.y;
+		}
+	}
+	STAMP(5);
+
+	// ---- top-nm selection (check-domain values) ----------------------------------------------------------------------
 	// (a) a 256-bucket histogram of [lmin, mtop] (LDS atomics + DPP prefix sum) finds the bucket that holds the nm-th best
 	// value -- bucketing only has to be monotone, so its arithmetic needs no care; (b) a ballot quickselect, restricted to
 	// that bucket, finds the cut exactly; ties at the cut are resolved by symbol, higher first (:1731).
 	int n0[4] = {0, 0, 0, 0}; // entries with an even check-domain symbol per edge (they come first in the list)
 	if (NC >= 2) { // conf(nm,1) needs no lists: it is contained in conf(q,1)
 		int bk[4][4];
-		int *H = (int *)U; // [256 buckets][4 edges] (spans U and P); lane l reads buckets 4l .. 4l+3
+		int *H = (int *)B0; // [4 edges][256 buckets] (spans B0 and B1); lane l reads buckets 4l .. 4l+3 of every edge
+		WSYNC();
 		{
 			int4 z4 = {0, 0, 0, 0};
 #pragma unroll
-			for (int i = 0; i < 4; i++) ((int4 *)H)[lane * 4 + i] = z4;
+			for (int i = 0; i < 4; i++) ((int4 *)H)[i * 64 + lane] = z4;
 		}
-		__syncthreads();
+		WSYNC();
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const double range = mtop[j] - lmin[j];
@@ -359,17 +456,21 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 				const double d = (mtop[j] - v[j][i]) * scale;
 				int bi = (int)dmin(d, 255.0);
 				bk[j][i] = (v[j][i] >= lmin[j]) ? bi : 256;
-				if (bk[j][i] < 256) atomicAdd(&H[bk[j][i] * 4 + j], 1);
+				if (bk[j][i] < 256) atomicAdd(&H[j * 256 + bk[j][i]], 1);
 			}
 		}
-		__syncthreads();
+		WSYNC();
 		int hc[4][4]; // [bucket slot of this lane][edge]
 #pragma unroll
-		for (int i = 0; i < 4; i++) {
-			const int4 h4 = ((int4 *)H)[lane * 4 + i];
-			hc[i][0] = h4.x; hc[i][1] = h4.y; hc[i][2] = h4.z; hc[i][3] = h4.w;
+		for (int j = 0; j < 4; j++) {
+			const int4 h4 = ((int4 *)H)[j * 64 + lane];
+			hc[0][j] = h4.x; hc[1][j] = h4.y; hc[2][j] = h4.z; hc[3][j] = h4.w;
 		}
 		STAMP(2);
+		// list entry fields of the lane's four slots: symbol and gather offset are the same for every edge
+		int2 tt2[4];
+#pragma unroll
+		for (int i = 0; i < 4; i++) { tt2[i].x = sym_of(lane, i); tt2[i].y = (sym_of(lane, i) & 0xFE) << 3; }
 		// per edge: locate the cut bucket, settle the members, compact them into the list image
 		// [even-symbol group | odd-symbol group]
 #pragma unroll
@@ -397,117 +498,59 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 					select_step(v[j], NM, ss);
 					STAMP_COUNT(9);
 				}
-				finish_members(ss, NM, member);
+				finish_members(ss, NM, member, g.c_hinv[c0 + j], g.poly, lane);
 			}
-			// compaction straight from the (wave-uniform) member masks
-			uint64_t g0[4], g1[4];
-			int c0n = 0;
+			// compaction straight from the (wave-uniform) member masks: slots 0, 2 hold even symbols, slots 1, 3 odd ones
+			const int c0n = __popcll(member[0]), c2n = __popcll(member[2]), c1n = __popcll(member[1]);
+			const int ne = c0n + c2n;
+			n0[j] = ne;
+			ListEnt *Lj = lstp + j * NM;
+			const int base[4] = {0, ne, c0n, ne + c1n};
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
-				const uint64_t even = __ballot(((tp[j] >> (8 * i)) & 1u) == 0u);
-				g0[i] = member[i] & even;
-				g1[i] = member[i] & ~even;
-				c0n += __popcll(g0[i]);
-			}
-			n0[j] = c0n;
-			ListEnt *Lj = lstp + j * NMP;
-			int base0 = 0, base1 = c0n; // [even-symbol group | odd-symbol group], back to back
-#pragma unroll
-			for (int i = 0; i < 4; i++) {
-				const int sym = TSYM(j, i);
-				const int pe_ = base0 + prefix_count(g0[i]), po_ = base1 + prefix_count(g1[i]);
-				const int pos = (sym & 1) ? po_ : pe_;
+				const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(member[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)member[i], base[i]));
 				if (__builtin_amdgcn_inverse_ballot_w64(member[i])) {
-					ListEnt e;
-					e.v = v[j][i];
-					e.t = sym;
-					e.tt = (sym & 0xFE) << 3;
-					Lj[pos] = e;
+					Lj[pos].v = v[j][i];
+					*(int2 *)&Lj[pos].t = tt2[i];
 				}
-				base0 += __popcll(g0[i]);
-				base1 += __popcll(g1[i]);
 			}
 		}
 	}
-	__syncthreads();
+	WSYNC();
 	STAMP(4);
 
-	// ---- conf(q,1): one edge deviates to any symbol, the others stay at rank 0 (:894) ---------------------------
-	double S[4][4];
-#pragma unroll
-	for (int x = 0; x < 4; x++)
-#pragma unroll
-		for (int i = 0; i < 4; i++) S[x][i] = -NBL_DBL_MAX;
-	const int ztot = ztop[0] ^ ztop[1] ^ ztop[2] ^ ztop[3];
-#pragma unroll
-	for (int j = 0; j < 4; j++) {
-		__syncthreads();
-#pragma unroll
-		for (int i = 0; i < 4; i++) U[TSYM(j, i)] = v[j][i];
-		__syncthreads();
-#pragma unroll
-		for (int x = 0; x < 4; x++) {
-			if (x == j) continue;
-			const int shift = ztot ^ ztop[x] ^ ztop[j];
-			// U[s ^ shift] for the lane's four symbols: two 16-byte reads (the XOR permutes 16-byte slots; bit 0 swaps inside a slot)
-			const int ad = (lane << 4) ^ ((shift & 0xFE) << 3);
-			const double2 ra = *(const double2 *)((const char *)U + ad), rb = *(const double2 *)((const char *)U + (ad ^ 1024));
-			const bool sw = shift & 1;
-			const double uu[4] = {sw ? ra.y : ra.x, sw ? ra.x : ra.y, sw ? rb.y : rb.x, sw ? rb.x : rb.y};
-#pragma unroll
-			for (int i = 0; i < 4; i++) {
-				double acc = 0.0;
-				const double u = uu[i];
-#pragma unroll
-				for (int o = 0; o < 4; o++) {
-					if (o == x) continue;
-					acc = acc + ((o == j) ? u : mtop[o]);
-				}
-				S[x][i] = dmax(S[x][i], acc);
-			}
-		}
-	}
-	STAMP(5);
-
-	// ---- conf(nm,nc >= 3): truncated max-plus convolutions; outputs 3,2 share P = e0 (+) e1 ----------------------
-	const int lane16 = lane << 4;
+	// ---- conf(nm,nc): truncated max-plus convolutions --------------------------------------------------------------
 	// dst[t_a ^ t_b ^ sxor] = max over the nm x nm entry pairs of (v_a + bias) + v_b   (bias = 0: plain pair convolution)
+	constexpr int PER = 64 >> LOGNM, ROUNDS = (NM << LOGNM) >> 6;
 	auto pair_scatter = [&](double *dst, int ja, int jb, double bias, int sxor) {
-		__syncthreads();
+		WSYNC();
 		double2 ninf;
 		ninf.x = NBL_NEG_INF;
 		ninf.y = NBL_NEG_INF;
 		((double2 *)dst)[lane] = ninf;
 		((double2 *)dst)[64 + lane] = ninf;
-		ListEnt ea = lstp[ja * NMP + (lane & (NM - 1))];
+		ListEnt ea = lstp[ja * NM + (lane & (NM - 1))];
 		ea.v = ea.v + bias;
 		ea.t ^= sxor;
-		__syncthreads();
-		constexpr int PER = 64 >> LOGNM, ROUNDS = (NM << LOGNM) >> 6;
+		WSYNC();
 #pragma unroll
 		for (int it = 0; it < ROUNDS; it++) {
-			const ListEnt eb = lstp[jb * NMP + it * PER + (lane >> LOGNM)];
+			const ListEnt eb = lstp[jb * NM + it * PER + (lane >> LOGNM)];
 			__hip_atomic_fetch_max(&dst[ea.t ^ eb.t], ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
-		__syncthreads();
+		WSYNC();
 	};
 	// same, accumulating into dst without clearing it
 	auto pair_scatter_more = [&](double *dst, int ja, int jb, double bias, int sxor) {
-		ListEnt ea = lstp[ja * NMP + (lane & (NM - 1))];
+		ListEnt ea = lstp[ja * NM + (lane & (NM - 1))];
 		ea.v = ea.v + bias;
 		ea.t ^= sxor;
-		constexpr int PER = 64 >> LOGNM, ROUNDS = (NM << LOGNM) >> 6;
 #pragma unroll
 		for (int it = 0; it < ROUNDS; it++) {
-			const ListEnt eb = lstp[jb * NMP + it * PER + (lane >> LOGNM)];
+			const ListEnt eb = lstp[jb * NM + it * PER + (lane >> LOGNM)];
 			__hip_atomic_fetch_max(&dst[ea.t ^ eb.t], ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
-		__syncthreads();
-	};
-	auto pair_conv = [&](int ja, int jb) {
-		pair_scatter(P, ja, jb, 0.0, 0);
-		((double2 *)P)[128 + lane] = ((const double2 *)P)[lane]; // mirror of the low half for the gathers
-		__syncthreads();
+		WSYNC();
 	};
 	// Sout[s] = max(Sout[s], src[s ^ sx] + add) for the lane's four symbols
 	auto fold = [&](const double *src, int sx, double add, double (&Sout)[4]) {
@@ -520,75 +563,68 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		Sout[2] = dmax(Sout[2], (sw ? rb.y : rb.x) + add);
 		Sout[3] = dmax(Sout[3], (sw ? rb.x : rb.y) + add);
 	};
-	// conf(nm,2) for output x with others o1 < o2 < o3 (P already holds o1 (+) o2): one of the three stays at rank 0 (:1769)
+	// conf(nm,2) for output x with others o1 < o2 < o3 (B0 already holds o1 (+) o2): one of the three stays at rank 0 (:1769)
 	auto conf_nc2 = [&](int x, int o1, int o2, int o3) {
-		fold(P, ztop[o3], mtop[o3], S[x]);                                   // (v1 + v2) + m3
-		pair_scatter(U, o2, o3, mtop[o1], ztop[o1]);                         // (m1 + v2) + v3
-		pair_scatter_more(U, o1, o3, mtop[o2], ztop[o2]);                    // (v1 + m2) + v3
+		fold(B0, ztop[o3], mtop[o3], S[x]);                                   // (v1 + v2) + m3
+		pair_scatter(B1, o2, o3, mtop[o1], ztop[o1]);                         // (m1 + v2) + v3
+		pair_scatter_more(B1, o1, o3, mtop[o2], ztop[o2]);                    // (v1 + m2) + v3
 		{
-			const double2 ra = ((const double2 *)U)[lane], rb = ((const double2 *)U)[64 + lane];
+			const double2 ra = ((const double2 *)B1)[lane], rb = ((const double2 *)B1)[64 + lane];
 			S[x][0] = dmax(S[x][0], ra.x); S[x][1] = dmax(S[x][1], ra.y);
 			S[x][2] = dmax(S[x][2], rb.x); S[x][3] = dmax(S[x][3], rb.y);
 		}
 	};
-	auto gather_conv = [&](int jc, double (&Sout)[4]) {
-		double a0 = NBL_NEG_INF, a1 = NBL_NEG_INF, a2 = NBL_NEG_INF, a3 = NBL_NEG_INF;
-		const char *Pb = (const char *)P;
-		const ListEnt *L = lstp + jc * NMP;
-		// entries [0, n0): even symbols, the lane's slot pairs line up; [n0, NM): odd symbols, the pairs are swapped.  Four entries
+	// NP max-plus gather convolutions over ONE list: acc[p][s] = max_k  P_p[s ^ t_k] + v_k, P_p = B0 + p * Q
+	auto gather_conv = [&](int jc, auto np_tag, double (&acc)[decltype(np_tag)::value][4]) {
+		constexpr int NP = decltype(np_tag)::value;
+		constexpr int UN = (NP == 1) ? 4 : 2; // entries per trip
+		const char *Pb = (const char *)B0;
+		const ListEnt *L = lstp + jc * NM;
+		// entries [0, n0): even symbols, the lane's slot pairs line up; [n0, NM): odd symbols, the pairs are swapped.  UN entries
 		// per trip, then the remainder one by one (no padding entries: every trip is real work)
-		auto run = [&](int k0, int k1, auto swapped) {
+		auto body = [&](const ListEnt &en, auto swapped) {
 			constexpr bool SW = decltype(swapped)::value;
+			const int ad = lane16 ^ en.tt, ad2 = ad ^ 1024;
+			double2 ra[NP], rb[NP];
+#pragma unroll
+			for (int p = 0; p < NP; p++) {
+				ra[p] = *(const double2 *)(Pb + p * (Q * 8) + ad);
+				rb[p] = *(const double2 *)(Pb + p * (Q * 8) + ad2);
+			}
+#pragma unroll
+			for (int p = 0; p < NP; p++) {
+				acc[p][0] = dmax(acc[p][0], (SW ? ra[p].y : ra[p].x) + en.v);
+				acc[p][1] = dmax(acc[p][1], (SW ? ra[p].x : ra[p].y) + en.v);
+				acc[p][2] = dmax(acc[p][2], (SW ? rb[p].y : rb[p].x) + en.v);
+				acc[p][3] = dmax(acc[p][3], (SW ? rb[p].x : rb[p].y) + en.v);
+			}
+		};
+		auto run = [&](int k0, int k1, auto swapped) {
 			int k = k0;
-			for (; k + 4 <= k1; k += 4) {
-				ListEnt en[4];
-				double2 ra[4], rb[4];
+			for (; k + UN <= k1; k += UN) {
+				ListEnt en[UN];
 #pragma unroll
-				for (int u = 0; u < 4; u++) en[u] = L[k + u]; // same address in every lane: LDS broadcast
+				for (int u = 0; u < UN; u++) en[u] = L[k + u]; // same address in every lane: LDS broadcast
 #pragma unroll
-				for (int u = 0; u < 4; u++) {
-					const int ad = lane16 ^ en[u].tt;
-					ra[u] = *(const double2 *)(Pb + ad);
-					rb[u] = *(const double2 *)(Pb + ad + 1024); // the other half (P[256..383] mirrors P[0..127])
-				}
-#pragma unroll
-				for (int u = 0; u < 4; u++) {
-					a0 = dmax(a0, (SW ? ra[u].y : ra[u].x) + en[u].v);
-					a1 = dmax(a1, (SW ? ra[u].x : ra[u].y) + en[u].v);
-					a2 = dmax(a2, (SW ? rb[u].y : rb[u].x) + en[u].v);
-					a3 = dmax(a3, (SW ? rb[u].x : rb[u].y) + en[u].v);
-				}
+				for (int u = 0; u < UN; u++) body(en[u], swapped);
 			}
-			for (; k < k1; k++) {
-				const ListEnt en = L[k];
-				const int ad = lane16 ^ en.tt;
-				const double2 ra = *(const double2 *)(Pb + ad), rb = *(const double2 *)(Pb + ad + 1024);
-				a0 = dmax(a0, (SW ? ra.y : ra.x) + en.v);
-				a1 = dmax(a1, (SW ? ra.x : ra.y) + en.v);
-				a2 = dmax(a2, (SW ? rb.y : rb.x) + en.v);
-				a3 = dmax(a3, (SW ? rb.x : rb.y) + en.v);
-			}
+			for (; k < k1; k++) body(L[k], swapped);
 		};
 		run(0, n0[jc], std::false_type{});
 		run(n0[jc], NM, std::true_type{});
-		Sout[0] = dmax(Sout[0], a0);
-		Sout[1] = dmax(Sout[1], a1);
-		Sout[2] = dmax(Sout[2], a2);
-		Sout[3] = dmax(Sout[3], a3);
 	};
-	// c2v[a] = shape(S[h_x a] - S[0]) (:899-916)
-	auto emit = [&](int x) {
-		double *Sx = U;
-		__syncthreads();
+	// c2v[a] = shape(S[h_x a] - S[0]) (:899-916): the output goes back to the variable domain through LDS
+	auto emit_stage = [&](int x, double *Sx) {
 		double2 s01, s23;
 		s01.x = S[x][0]; s01.y = S[x][1]; s23.x = S[x][2]; s23.y = S[x][3];
 		((double2 *)Sx)[lane] = s01;
 		((double2 *)Sx)[64 + lane] = s23;
-		__syncthreads();
+	};
+	auto emit_store = [&](int x, const double *Sx) {
 		const double s0 = Sx[0];
 		double y[4];
 #pragma unroll
-		for (int i = 0; i < 4; i++) y[i] = shape_llr(Sx[TSYM(x, i)] - s0, r.factor, r.offset);
+		for (int i = 0; i < 4; i++) y[i] = shape_llr(*(const double *)((const char *)Sx + TOFF(x, i)) - s0, r.factor, r.offset);
 		if (lane == 0) y[0] = 0.0;
 		double2 o01, o23;
 		o01.x = y[0]; o01.y = y[1]; o23.x = y[2]; o23.y = y[3];
@@ -598,53 +634,59 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	};
 
 	if (NC >= 3) {
-		pair_conv(0, 1);
+		// the three pair convolutions in one pass: B0 = e0 (+) e1, B1 = e0 (+) e2, B2 = e1 (+) e2
+		{
+			double2 ninf;
+			ninf.x = NBL_NEG_INF;
+			ninf.y = NBL_NEG_INF;
+#pragma unroll
+			for (int i = 0; i < 6; i++) ((double2 *)B0)[i * 64 + lane] = ninf;
+			const ListEnt ea0 = lstp[0 * NM + (lane & (NM - 1))], ea1 = lstp[1 * NM + (lane & (NM - 1))];
+			WSYNC();
+#pragma unroll
+			for (int it = 0; it < ROUNDS; it++) {
+				const ListEnt eb1 = lstp[1 * NM + it * PER + (lane >> LOGNM)], eb2 = lstp[2 * NM + it * PER + (lane >> LOGNM)];
+				__hip_atomic_fetch_max(&B0[ea0.t ^ eb1.t], ea0.v + eb1.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_fetch_max(&B1[ea0.t ^ eb2.t], ea0.v + eb2.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_fetch_max(&B2[ea1.t ^ eb2.t], ea1.v + eb2.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+			WSYNC();
+		}
 		STAMP(6);
-		gather_conv(2, S[3]);
-		gather_conv(3, S[2]);
+		// output 3 = (e0 (+) e1) (+) e2; outputs 2, 1, 0 = {e0 (+) e1, e0 (+) e2, e1 (+) e2} (+) e3 share the loop over list 3
+		{
+			double a3[1][4], a210[3][4];
+#pragma unroll
+			for (int i = 0; i < 4; i++) { a3[0][i] = S[3][i]; a210[0][i] = S[2][i]; a210[1][i] = S[1][i]; a210[2][i] = S[0][i]; }
+			gather_conv(2, std::integral_constant<int, 1>{}, a3);
+			gather_conv(3, std::integral_constant<int, 3>{}, a210);
+#pragma unroll
+			for (int i = 0; i < 4; i++) { S[3][i] = a3[0][i]; S[2][i] = a210[0][i]; S[1][i] = a210[1][i]; S[0][i] = a210[2][i]; }
+		}
 		STAMP(7);
-		emit(3);
-		emit(2);
-		STAMP(8);
-		pair_conv(0, 2);
-		STAMP(6);
-		gather_conv(3, S[1]);
-		STAMP(7);
-		emit(1);
-		STAMP(8);
-		pair_conv(1, 2);
-		STAMP(6);
-		gather_conv(3, S[0]);
-		STAMP(7);
-		emit(0);
-		STAMP(8);
 	} else if (NC == 2) {
-		pair_conv(0, 1);
+		pair_scatter(B0, 0, 1, 0.0, 0);
 		conf_nc2(3, 0, 1, 2);
-		STAMP(6);
-		emit(3);
-		STAMP(8);
 		conf_nc2(2, 0, 1, 3);
-		STAMP(6);
-		emit(2);
-		STAMP(8);
-		pair_conv(0, 2);
+		pair_scatter(B0, 0, 2, 0.0, 0);
 		conf_nc2(1, 0, 2, 3);
-		STAMP(6);
-		emit(1);
-		STAMP(8);
-		pair_conv(1, 2);
+		pair_scatter(B0, 1, 2, 0.0, 0);
 		conf_nc2(0, 1, 2, 3);
 		STAMP(6);
-		emit(0);
-		STAMP(8);
-	} else {
-		emit(3);
-		emit(2);
-		emit(1);
-		emit(0);
-		STAMP(8);
 	}
+	WSYNC();
+	emit_stage(3, B0);
+	emit_stage(2, B1);
+	emit_stage(1, B2);
+	WSYNC();
+	emit_store(3, B0);
+	emit_store(2, B1);
+	emit_store(1, B2);
+	WSYNC();
+	emit_stage(0, B0);
+	WSYNC();
+	emit_store(0, B0);
+	STAMP(8);
 
 #ifdef NBL_EMS_STAMPS
 	if (st_on && lane == 0) {
@@ -654,18 +696,18 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 #endif
 #undef STAMP
 #undef STAMP_COUNT
-#undef TSYM
+#undef TOFF
 }
 
 bool nbl_ems256_applicable(const NblGraphDev &g, bool all_dc4, int nm, int nc)
 {
-	return g.q == 256 && all_dc4 && nc >= 1 && (nm == 8 || nm == 16 || nm == 32);
+	return g.q == 256 && all_dc4 && nc >= 1 && (nm == 8 || nm == 16 || nm == 32) && g.ems_toff != nullptr;
 }
 
-size_t nbl_ems256_lds_bytes(int nm) { return 2 * Q * 8 + Q / 2 * 8 + (size_t)4 * nm * 16; }
+size_t nbl_ems256_lds_bytes(int nm) { return 3 * Q * 8 + (size_t)4 * nm * 16; }
 
 template <int NM, bool FUSED>
-static void launch_nc(int nc, dim3 grid, dim3 block, size_t lds, hipStream_t st, const NblGraphDev &g, const NblWork &w, const NblRun &r)
+static void launch_nc(int nc, dim3 grid, dim3 block, hipStream_t st, const NblGraphDev &g, const NblWork &w, const NblRun &r)
 {
 	if (nc >= 3) cn_ems_q256_dc4_kernel<NM, FUSED, 3><<<grid, block, 0, st>>>(g, w, r);
 	else if (nc == 2) cn_ems_q256_dc4_kernel<NM, FUSED, 2><<<grid, block, 0, st>>>(g, w, r);
@@ -675,19 +717,18 @@ static void launch_nc(int nc, dim3 grid, dim3 block, size_t lds, hipStream_t st,
 hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 {
 	dim3 grid((unsigned)((long long)((r.B + 7) / 8) * 8 * g.M)), block(64);
-	const size_t lds = nbl_ems256_lds_bytes(r.nm);
 	if (fused) {
 		switch (r.nm) {
-		case 8: launch_nc<8, true>(r.nc, grid, block, lds, st, g, w, r); break;
-		case 16: launch_nc<16, true>(r.nc, grid, block, lds, st, g, w, r); break;
-		case 32: launch_nc<32, true>(r.nc, grid, block, lds, st, g, w, r); break;
+		case 8: launch_nc<8, true>(r.nc, grid, block, st, g, w, r); break;
+		case 16: launch_nc<16, true>(r.nc, grid, block, st, g, w, r); break;
+		case 32: launch_nc<32, true>(r.nc, grid, block, st, g, w, r); break;
 		default: return hipErrorInvalidValue;
 		}
 	} else {
 		switch (r.nm) {
-		case 8: launch_nc<8, false>(r.nc, grid, block, lds, st, g, w, r); break;
-		case 16: launch_nc<16, false>(r.nc, grid, block, lds, st, g, w, r); break;
-		case 32: launch_nc<32, false>(r.nc, grid, block, lds, st, g, w, r); break;
+		case 8: launch_nc<8, false>(r.nc, grid, block, st, g, w, r); break;
+		case 16: launch_nc<16, false>(r.nc, grid, block, st, g, w, r); break;
+		case 32: launch_nc<32, false>(r.nc, grid, block, st, g, w, r); break;
 		default: return hipErrorInvalidValue;
 		}
 	}
