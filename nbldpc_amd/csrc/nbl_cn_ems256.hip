@@ -31,7 +31,9 @@ namespace {
 
 constexpr int Q = 256;
 
-struct __attribute__((aligned(16))) ListEnt { double v; int t; int tt; };   // tt = (t & 0xFE) << 3: byte offset XOR of the gather
+// list entry of a check-domain symbol t: value + {t8 = 8 t: byte offset of the symbol, tt = (t & 0xFE) << 3: byte-offset XOR of the
+// gather}; values and offset pairs live in separate arrays (two 8-byte stores from registers that already exist)
+struct ListEnt { double v; int t8; int tt; };
 
 // One wave per workgroup: LDS operations of one wave execute in issue order, so phases that hand data over through LDS only
 // need the COMPILER to keep the order -- no s_barrier, no drain of the LDS queue.
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	constexpr int LOGNM = (NM == 8) ? 3 : (NM == 16) ? 4 : 5;
 	// static LDS: its base is a compile-time constant, so computed addresses fold into the ds_* offset fields (with `extern
 	// __shared__` every computed address pays a v_add with the link-time base)
-	__shared__ __attribute__((aligned(16))) char smem[3 * Q * 8 + 4 * NM * 16];
+	__shared__ __attribute__((aligned(16))) char smem[3 * Q * 8 + 4 * NM * 8 + 4 * NM * 8];
 	const int lane = lane_id();
 	// XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  All checks of
 	// a codeword are given to ONE XCD, so the second read of every L_ch / c2v vector (each is used by two checks) can hit
@@ -269,7 +271,17 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 
 	// three q-vectors: staging of the incoming vectors | histogram (B0..B1) | the three pair convolutions | staging of the outputs
 	double *const B0 = (double *)smem, *const B1 = B0 + Q, *const B2 = B1 + Q;
-	ListEnt *const lstp = (ListEnt *)(B2 + Q); // [4][NM]  the nm best of every edge: [even-symbol group | odd-symbol group]
+	// the nm best of every edge, [even-symbol group | odd-symbol group]: values [4][NM], offsets {t8, tt} [4][NM]
+	double *const lstv = B2 + Q;
+	int2 *const lstt = (int2 *)(lstv + 4 * NM);
+	auto list_at = [&](int j, int k) {
+		ListEnt e;
+		e.v = lstv[j * NM + k];
+		const int2 o = lstt[j * NM + k];
+		e.t8 = o.x;
+		e.tt = o.y;
+		return e;
+	};
 
 	// per-section cycle stamps (tools/stamps.py): compiled in only with -DNBL_EMS_STAMPS -- the accumulators
 	// live in SGPRs for the whole kernel and push the selection code into SGPR spills
@@ -375,7 +387,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		// 64 distinct entries are >= the smallest lane maximum, so the nm-th best (nm <= 64) is too; the key of that minimum is
 		// taken one float step down (rounding may have gone up) -- any lower bound will do
 		const double lf = dmin((double)unkey32(wave_min_i32(k)), 3.0e38); // (a float infinity must not become the bound)
-		lmin[j] = (lf - __builtin_fabs(lf) * 0x1p-22) - 0x1p-120;
+		lmin[j] = ((lf - (mtop[j] - lf) * 0x1p-20) - __builtin_fabs(lf) * 0x1p-22) - 0x1p-120; // (margins: float rounding, rcp in the bucket scale)
 		uint64_t eqm[4];
 #pragma unroll
 		for (int i = 0; i < 4; i++) eqm[i] = __ballot(v[j][i] == mtop[j]);
@@ -407,22 +419,25 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		for (int x = 0; x < 4; x++) {
 			if (x == j) continue;
 			const int shift = ztot ^ ztop[x] ^ ztop[j];
-			// U[s ^ shift] for the lane's four symbols: two 16-byte reads (the XOR permutes 16-byte slots; bit 0 swaps inside a slot)
+			// U[s ^ shift] for the lane's four symbols: two 16-byte reads (the XOR permutes 16-byte slots; bit 0 swaps inside a
+			// slot -- a wave-uniform property, resolved by a branch rather than by eight selects)
 			const int ad = lane16 ^ ((shift & 0xFE) << 3);
 			const double2 ra = *(const double2 *)(Uj + ad), rb = *(const double2 *)(Uj + (ad ^ 1024));
-			const bool sw = shift & 1;
-			const double uu[4] = {sw ? ra.y : ra.x, sw ? ra.x : ra.y, sw ? rb.y : rb.x, sw ? rb.x : rb.y};
+			auto upd = [&](double u0, double u1, double u2, double u3) {
+				const double uu[4] = {u0, u1, u2, u3};
 #pragma unroll
-			for (int i = 0; i < 4; i++) {
-				double acc = 0.0;
-				const double u = uu[i];
+				for (int i = 0; i < 4; i++) {
+					double acc = 0.0;
 #pragma unroll
-				for (int o = 0; o < 4; o++) {
-					if (o == x) continue;
-					acc = acc + ((o == j) ? u : mtop[o]);
+					for (int o = 0; o < 4; o++) {
+						if (o == x) continue;
+						acc = acc + ((o == j) ? uu[i] : mtop[o]);
+					}
+					S[x][i] = dmax(S[x][i], acc);
 				}
-				S[x][i] = dmax(S[x][i], acc);
-			}
+			};
+			if (shift & 1) upd(ra.y, ra.x, rb.y, rb.x);
+			else upd(ra.x, ra.y, rb.x, rb.y);
 		}
 		if (NC >= 2) {
 			const double2 d0 = *(const double2 *)(Uj + lane16), d1 = *(const double2 *)(Uj + lane16 + 1024);
@@ -448,14 +463,13 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		WSYNC();
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
-			const double range = mtop[j] - lmin[j];
-			// bucketing only has to be monotone and the same in every lane: the hardware reciprocal will do (an IEEE division is ~14 instructions)
-			const double scale = range > 0.0 ? 256.0 * __builtin_amdgcn_rcp(range) : 0.0;
+			// bucketing only has to be monotone and the same in every lane: the hardware reciprocal will do (an IEEE division is
+			// ~14 instructions).  lmin lies strictly below every lane maximum, so range > 0, entries >= the smallest lane maximum land
+			// in buckets 0..255 and everything below lmin is clamped to 256 = "not counted"
+			const double scale = 256.0 * __builtin_amdgcn_rcp(mtop[j] - lmin[j]);
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
-				const double d = (mtop[j] - v[j][i]) * scale;
-				int bi = (int)dmin(d, 255.0);
-				bk[j][i] = (v[j][i] >= lmin[j]) ? bi : 256;
+				bk[j][i] = (int)dmin((mtop[j] - v[j][i]) * scale, 256.0);
 				if (bk[j][i] < 256) atomicAdd(&H[j * 256 + bk[j][i]], 1);
 			}
 		}
@@ -470,7 +484,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		// list entry fields of the lane's four slots: symbol and gather offset are the same for every edge
 		int2 tt2[4];
 #pragma unroll
-		for (int i = 0; i < 4; i++) { tt2[i].x = sym_of(lane, i); tt2[i].y = (sym_of(lane, i) & 0xFE) << 3; }
+		for (int i = 0; i < 4; i++) { tt2[i].x = sym_of(lane, i) << 3; tt2[i].y = (sym_of(lane, i) & 0xFE) << 3; }
 		// per edge: locate the cut bucket, settle the members, compact them into the list image
 		// [even-symbol group | odd-symbol group]
 #pragma unroll
@@ -479,20 +493,24 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			const int cum = wave_scan_add(tot);
 			const uint64_t reach = __ballot(cum >= NM);
 			const int lstar = reach ? __builtin_ctzll(reach) : 63;
-			// every lane works out which of its four buckets would be the cut; the cut lane's answer is read back
-			const int pre = cum - tot, s0 = pre + hc[0][j], s1 = s0 + hc[1][j], s2 = s1 + hc[2][j];
+			// the cut lane's four bucket counts and its running total: which of its buckets holds the nm-th entry is scalar work
+			const int cl = __builtin_amdgcn_readlane(cum, lstar);
+			const int q1 = __builtin_amdgcn_readlane(hc[1][j], lstar),
+			          q2 = __builtin_amdgcn_readlane(hc[2][j], lstar), q3 = __builtin_amdgcn_readlane(hc[3][j], lstar);
+			const int s0 = cl - q3 - q2 - q1, s1 = cl - q3 - q2, s2 = cl - q3;
 			const int bsel = (s0 >= NM) ? 0 : (s1 >= NM) ? 1 : (s2 >= NM) ? 2 : 3;
-			const int upto = (s0 >= NM) ? s0 : (s1 >= NM) ? s1 : (s2 >= NM) ? s2 : cum; // entries up to and including the cut bucket
-			const int bstar = 4 * lstar + __builtin_amdgcn_readlane(bsel, lstar);
-			const bool exact = __builtin_amdgcn_readlane(upto, lstar) == NM; // the cut bucket ends exactly at the nm-th entry
+			const int upto = (s0 >= NM) ? s0 : (s1 >= NM) ? s1 : (s2 >= NM) ? s2 : cl; // entries up to and including the cut bucket
+			const int bstar = 4 * lstar + bsel;
+			const bool exact = reach && upto == NM; // the cut bucket ends exactly at the nm-th entry
 			uint64_t member[4];
 			if (exact) {
 #pragma unroll
 				for (int i = 0; i < 4; i++) member[i] = __ballot(bk[j][i] <= bstar);
 			} else {
+				// (no bucket reaches nm -- cannot happen with finite inputs: every entry is a candidate)
 				SelState ss;
 #pragma unroll
-				for (int i = 0; i < 4; i++) { ss.cand[i] = __ballot(bk[j][i] == bstar); ss.gt[i] = ss.eq[i] = 0; }
+				for (int i = 0; i < 4; i++) { ss.cand[i] = reach ? __ballot(bk[j][i] == bstar) : ~0ull; ss.gt[i] = ss.eq[i] = 0; }
 				ss.done = 0;
 				for (int guard = 0; guard < 300 && !ss.done; guard++) {
 					select_step(v[j], NM, ss);
@@ -504,14 +522,13 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			const int c0n = __popcll(member[0]), c2n = __popcll(member[2]), c1n = __popcll(member[1]);
 			const int ne = c0n + c2n;
 			n0[j] = ne;
-			ListEnt *Lj = lstp + j * NM;
-			const int base[4] = {0, ne, c0n, ne + c1n};
+			const int base[4] = {j * NM, j * NM + ne, j * NM + c0n, j * NM + ne + c1n};
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
 				const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(member[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)member[i], base[i]));
 				if (__builtin_amdgcn_inverse_ballot_w64(member[i])) {
-					Lj[pos].v = v[j][i];
-					*(int2 *)&Lj[pos].t = tt2[i];
+					lstv[pos] = v[j][i];
+					lstt[pos] = tt2[i];
 				}
 			}
 		}
@@ -522,6 +539,9 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	// ---- conf(nm,nc): truncated max-plus convolutions --------------------------------------------------------------
 	// dst[t_a ^ t_b ^ sxor] = max over the nm x nm entry pairs of (v_a + bias) + v_b   (bias = 0: plain pair convolution)
 	constexpr int PER = 64 >> LOGNM, ROUNDS = (NM << LOGNM) >> 6;
+	// list position of the lane's fixed operand: neighbouring lanes alternate between the front (even symbols) and the back (odd
+	// symbols) of the list -- a run of 16 even symbols would only reach half of the LDS banks of the scatter
+	const int apos = (lane & 1) ? (NM - 1) - ((lane & (NM - 1)) >> 1) : ((lane & (NM - 1)) >> 1);
 	auto pair_scatter = [&](double *dst, int ja, int jb, double bias, int sxor) {
 		WSYNC();
 		double2 ninf;
@@ -529,26 +549,26 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		ninf.y = NBL_NEG_INF;
 		((double2 *)dst)[lane] = ninf;
 		((double2 *)dst)[64 + lane] = ninf;
-		ListEnt ea = lstp[ja * NM + (lane & (NM - 1))];
+		ListEnt ea = list_at(ja, apos);
 		ea.v = ea.v + bias;
-		ea.t ^= sxor;
+		ea.t8 ^= sxor << 3;
 		WSYNC();
 #pragma unroll
 		for (int it = 0; it < ROUNDS; it++) {
-			const ListEnt eb = lstp[jb * NM + it * PER + (lane >> LOGNM)];
-			__hip_atomic_fetch_max(&dst[ea.t ^ eb.t], ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			const ListEnt eb = list_at(jb, it * PER + (lane >> LOGNM));
+			__hip_atomic_fetch_max((double *)((char *)dst + (ea.t8 ^ eb.t8)), ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 		WSYNC();
 	};
 	// same, accumulating into dst without clearing it
 	auto pair_scatter_more = [&](double *dst, int ja, int jb, double bias, int sxor) {
-		ListEnt ea = lstp[ja * NM + (lane & (NM - 1))];
+		ListEnt ea = list_at(ja, apos);
 		ea.v = ea.v + bias;
-		ea.t ^= sxor;
+		ea.t8 ^= sxor << 3;
 #pragma unroll
 		for (int it = 0; it < ROUNDS; it++) {
-			const ListEnt eb = lstp[jb * NM + it * PER + (lane >> LOGNM)];
-			__hip_atomic_fetch_max(&dst[ea.t ^ eb.t], ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			const ListEnt eb = list_at(jb, it * PER + (lane >> LOGNM));
+			__hip_atomic_fetch_max((double *)((char *)dst + (ea.t8 ^ eb.t8)), ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 		WSYNC();
 	};
@@ -579,7 +599,6 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		constexpr int NP = decltype(np_tag)::value;
 		constexpr int UN = (NP == 1) ? 4 : 2; // entries per trip
 		const char *Pb = (const char *)B0;
-		const ListEnt *L = lstp + jc * NM;
 		// entries [0, n0): even symbols, the lane's slot pairs line up; [n0, NM): odd symbols, the pairs are swapped.  UN entries
 		// per trip, then the remainder one by one (no padding entries: every trip is real work)
 		auto body = [&](const ListEnt &en, auto swapped) {
@@ -604,11 +623,11 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			for (; k + UN <= k1; k += UN) {
 				ListEnt en[UN];
 #pragma unroll
-				for (int u = 0; u < UN; u++) en[u] = L[k + u]; // same address in every lane: LDS broadcast
+				for (int u = 0; u < UN; u++) en[u] = list_at(jc, k + u); // same address in every lane: LDS broadcast
 #pragma unroll
 				for (int u = 0; u < UN; u++) body(en[u], swapped);
 			}
-			for (; k < k1; k++) body(L[k], swapped);
+			for (; k < k1; k++) body(list_at(jc, k), swapped);
 		};
 		run(0, n0[jc], std::false_type{});
 		run(n0[jc], NM, std::true_type{});
@@ -641,14 +660,14 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			ninf.y = NBL_NEG_INF;
 #pragma unroll
 			for (int i = 0; i < 6; i++) ((double2 *)B0)[i * 64 + lane] = ninf;
-			const ListEnt ea0 = lstp[0 * NM + (lane & (NM - 1))], ea1 = lstp[1 * NM + (lane & (NM - 1))];
+			const ListEnt ea0 = list_at(0, apos), ea1 = list_at(1, apos);
 			WSYNC();
 #pragma unroll
 			for (int it = 0; it < ROUNDS; it++) {
-				const ListEnt eb1 = lstp[1 * NM + it * PER + (lane >> LOGNM)], eb2 = lstp[2 * NM + it * PER + (lane >> LOGNM)];
-				__hip_atomic_fetch_max(&B0[ea0.t ^ eb1.t], ea0.v + eb1.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				__hip_atomic_fetch_max(&B1[ea0.t ^ eb2.t], ea0.v + eb2.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				__hip_atomic_fetch_max(&B2[ea1.t ^ eb2.t], ea1.v + eb2.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				const ListEnt eb1 = list_at(1, it * PER + (lane >> LOGNM)), eb2 = list_at(2, it * PER + (lane >> LOGNM));
+				__hip_atomic_fetch_max((double *)((char *)B0 + (ea0.t8 ^ eb1.t8)), ea0.v + eb1.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_fetch_max((double *)((char *)B1 + (ea0.t8 ^ eb2.t8)), ea0.v + eb2.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_fetch_max((double *)((char *)B2 + (ea1.t8 ^ eb2.t8)), ea1.v + eb2.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
 			WSYNC();
 		}

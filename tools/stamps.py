@@ -21,7 +21,7 @@ lib.nbl_debug_stamps(dec.h, 1, None)
 dec.decode(L)
 lib.nbl_debug_stamps(dec.h, 0, out)
 n = out[15]
-names = ["load+permute", "rank0", "histogram", "quickselect", "compact+lists", "conf(q,1)", "pair scatter", "gather conv", "emit"]
+names = ["load + VN pass", "rank 0", "histogram", "(unused)", "cut + lists", "staging + conf(q,1)", "pair scatters", "gather convs", "emit"]
 tot = sum(out[i] for i in range(9))
 print("quickselect loop iterations per check:", out[9] / n)
 for i, nme in enumerate(names):
