@@ -10,10 +10,11 @@ N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ... ben
 decodes its own batch (independent frames, no data-path collective: SURVEY 8e), scaling is weak.
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant kernel (EMS check node): algorithmic bytes per launch / mean launch time (HIP events on
-                the launch stream inside the timed region) against the 8 TB/s HBM peak
-  cpu_baseline  the compiled reference itself (oracle/_ref, kind "reference") timed on this host's cores on a bounded
-                sample of the same workload (rank 0, N=1 only); cpu_baseline_port = the oracle's literal restatement
+  roofline      dominant kernel (fused EMS iteration): algorithmic bytes per launch / mean launch time (HIP events on
+                the launch stream inside the timed region) against the 8 TB/s HBM peak; `traffic` / `hbm_actual_GBps` = what
+                the kernel really moves (committed PMC passes), `limiter` = what it waits for
+  cpu_baseline  the compiled reference itself (oracle/_ref, kind "reference") on this host's cores, decode loop only, on a
+                bounded sample of the same workload (rank 0, N=1 only); cpu_baseline_port = the oracle's literal restatement
                 on codewords of the same batch (kind "port"; also the fallback when oracle/_ref is absent)
 """
 import argparse
@@ -78,10 +79,13 @@ def cpu_baseline_port(nb, L_host, nm, nc, max_iter, threads):
                       f"reference EMS (gcc -O2), {dt:.1f} s wall"}
 
 
-def cpu_baseline_reference(nb, nm, nc, max_iter, threads, frames=2):
+def cpu_baseline_reference(nb, nm, nc, max_iter, threads, frames=4):
     """The COMPILED REFERENCE itself (oracle/_ref/ref_driver_O2, built in the build container from the unmodified sources; the
     binary travels, the sources do not), one process per core like the reference's one CNBLDPC per lane.  The reference has no
-    fixed-iteration mode, so it is run at Eb/N0 = -3 dB where every frame fails and all `max_iter` iterations execute."""
+    fixed-iteration mode, so it is run at Eb/N0 = -3 dB where every frame fails and all `max_iter` iterations execute.
+    Only the simulation of the Eb/N0 point is timed -- the CPU seconds the reference itself reports per point
+    (clock() from CSimulation::ClearSimuCount, Simulation.cpp:222-225 / :357) -- not process start, table loads or
+    CNBLDPC::Initial; the rate is the sum over the processes of frames / CPU seconds (one process per core)."""
     import subprocess
     import tempfile
     from nbldpc_amd.profiles import profile_text
@@ -100,8 +104,8 @@ def cpu_baseline_reference(nb, nm, nc, max_iter, threads, frames=2):
                                  min_sim_cycle=frames - 1, seed=173 + k))
         procs.append(subprocess.Popen([exe, "fer", prof], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
     outs = [p.communicate()[0] for p in procs]
-    dt = time.time() - t0
-    done = 0
+    wall = time.time() - t0
+    done, rate, cpu_max = 0, 0.0, 0.0
     for o in outs:
         for line in o.splitlines():
             if line.startswith("{"):
@@ -109,17 +113,24 @@ def cpu_baseline_reference(nb, nm, nc, max_iter, threads, frames=2):
                 if r["errFrame"] != r["frames"]:
                     return None  # a frame converged early: not a fixed-iteration measurement
                 done += int(r["frames"])
+                rate += r["frames"] / r["cpu_s"]
+                cpu_max = max(cpu_max, r["cpu_s"])
     if done == 0:
         return None
-    return {"value": done / dt, "unit": "codewords/s", "cores": threads, "kind": "reference",
+    return {"value": rate, "unit": "codewords/s", "cores": threads, "kind": "reference",
             "sample": f"{done} codewords ({threads} processes x {frames}), compiled reference (g++ -O2) EMS nm={nm} nc={nc}, Eb/N0 -3 dB so "
-                      f"all {max_iter} iterations run, {dt:.1f} s wall"}
+                      f"all {max_iter} iterations run; decode loop only ({cpu_max:.1f} CPU s per process as the reference reports them; "
+                      f"{wall:.1f} s wall incl. set-up)"}
+
+
+PMC_SUMMARY = os.path.join("profiles", "r02_summary.json")
 
 
 def pmc_traffic(fused, B):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_summary.json: FETCH_SIZE and
-    WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md), scaled from the profiled batch of 16384."""
-    path = os.path.join(ROOT, "profiles", "r01_summary.json")
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the run, so this is NOT measured live:
+    it is taken from the committed rocprofv3 passes of this same command (profiles/r02_summary.json: FETCH_SIZE and WRITE_SIZE in
+    separate --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md), scaled from the profiled batch of 16384."""
+    path = os.path.join(ROOT, PMC_SUMMARY)
     if not fused or not os.path.exists(path):
         return None
     for name, v in json.load(open(path)).get("hbm_pmc", {}).items():
@@ -149,18 +160,9 @@ def main():
     import torch
     import nbldpc_amd as nb
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if args.same_device:
-            local_rank = 0
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=args.backend)
+    from nbldpc_amd import ranks
+    rk = ranks.init(args.backend, args.same_device)
+    world, rank, local_rank = rk.world, rk.rank, rk.local_rank
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -188,26 +190,21 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ms_cn = ms_vn = ms_syn = 0.0
-    n_cn = 0
-    for _ in range(args.steps):
+    timing = {"vn": 0.0, "syn": 0.0, "cn": 0.0, "n_cn": 0}
+
+    def timed_step():
         step()
         ms, launches = dec.last_timing()  # HIP events recorded on the launch stream around every kernel
-        ms_vn += ms[0]; ms_syn += ms[1]; ms_cn += ms[2]; n_cn += launches[2]
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        timing["vn"] += ms[0]; timing["syn"] += ms[1]; timing["cn"] += ms[2]; timing["n_cn"] += launches[2]
+
+    # barrier + torch.cuda.synchronize() on both sides, MAX over ranks (nbldpc_amd/ranks.py)
+    dt = ranks.timed(rk, timed_step, args.steps, torch.cuda.synchronize)
+    ms_vn, ms_syn, ms_cn, n_cn = timing["vn"], timing["syn"], timing["cn"], timing["n_cn"]
+    # whole-job sanity counters: every rank's per-lane (converged, decoded word == transmitted word) flags, gathered in lane order
+    lane_flags = torch.stack([conv.to(torch.float64), (out == tx_dev).all(dim=1).to(torch.float64)], dim=1).cpu().numpy()
+    # (ranks decode equal batches: global lane index = rank * B + lane)
+    all_flags = ranks.gather_lane_counters(rk, lane_flags, B * world)
+    n_conv, n_correct = ranks.sum_in_lane_order(all_flags)
 
     total_cw = B * args.steps * world
     value = total_cw / dt
@@ -222,6 +219,7 @@ def main():
     cn_bytes_launch = B * (bytes_iter if fused else 8 * (q - 1) * 2 * E)
     cn_ms = ms_cn / max(n_cn, 1)
     cn_gbs = cn_bytes_launch / (cn_ms * 1e-3) / 1e9 if cn_ms > 0 else 0.0
+    traffic = pmc_traffic(fused, B)
     res = {
         "metric": "decoded codewords/sec @ 50 iters, GF(256) N=512 rate-1/2",
         "value": value, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,12 +230,19 @@ def main():
                    "batch_per_gpu": B, "iters": args.iters, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
         "algorithmic_GBps_whole_job": total_cw * bytes_cw / dt / 1e9,
         "hbm_roofline_frac_whole_job": total_cw * bytes_cw / dt / 1e9 / (HBM_PEAK_GBS * world),
-        "converged_frac": float(conv.float().mean().item()),
-        # sanity on the decoded words themselves: frames whose output equals the transmitted codeword / converged frames
-        "frames_correct_frac": float((out == tx_dev).all(dim=1).float().mean().item()),
+        "converged_frac": n_conv / (B * world),
+        # sanity on the decoded words themselves: frames whose output equals the transmitted codeword (all ranks)
+        "frames_correct_frac": n_correct / (B * world),
         "phase_ms_per_step": {"vn": ms_vn / args.steps, "syndrome": ms_syn / args.steps, "cn": ms_cn / args.steps},
+        # `achieved` is the contract's figure: ALGORITHMIC bytes of one launch (8(q-1)(N+4E) per codeword and iteration,
+        # v2c round trip included) over the mean launch time.  The fused kernel never moves the v2c bytes: what it really pulls from
+        # HBM is `traffic` (N + 2E vectors in, E out, second reads served by L2), i.e. `hbm_actual_GBps` -- the kernel is limited by
+        # FP64 VALU issue and LDS bandwidth, HBM is the roofline it is priced against, not what it waits for.
         "roofline": {"kernel": "cn_ems_q256_dc4_kernel<32, fused>" if fused else "cn_ems_q256_dc4_kernel<32>", "bound": "hbm", "achieved": cn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": cn_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(fused, B), "bytes_per_launch": cn_bytes_launch, "ms_per_launch": cn_ms},
+                     "frac": cn_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": PMC_SUMMARY + " (rocprofv3 --pmc passes of this command; not measured in this run)" if traffic else None,
+                     "hbm_actual_GBps": (traffic / (cn_ms * 1e-3) / 1e9) if (traffic and cn_ms > 0) else None,
+                     "limiter": "fp64 valu issue + lds bandwidth (both ~75-80 % busy), not hbm",
+                     "bytes_per_launch": cn_bytes_launch, "ms_per_launch": cn_ms},
     }
     if rank == 0 and world == 1 and args.cpu_sample != 0:
         threads = os.cpu_count() or 1
@@ -254,8 +259,7 @@ def main():
     if rank == 0:
         print(json.dumps(res))
     dec.close()
-    if dist:
-        dist.destroy_process_group()
+    ranks.finish(rk)
 
 
 if __name__ == "__main__":

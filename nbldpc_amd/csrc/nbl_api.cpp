@@ -201,8 +201,18 @@ extern "C" nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_m
 				if (code->var_chk[e] == m) c_epos[ce] = e; // like ChkLinkDv
 			if (c_epos[ce] < 0) return fail_create(nullptr, NBL_ERR_ARG, "check-side edge without variable-side partner");
 		}
-	// primitive polynomial recovered from the table: x * x^(p-1) = x^p = poly - q
 	const int p = ilog2(q);
+	// shape limits of the kernels, refused here rather than at the first decode
+	if (params->method == NBL_METHOD_TEMS && p * maxdc > 32)
+		return fail_create(nullptr, NBL_ERR_UNSUPPORTED, "T-EMS: log2(q) * (largest check degree) must not exceed 32 (the trellis path code is one 32-bit word)");
+	if (params->method == NBL_METHOD_EMS) {
+		const int layers = (params->ems_nc >= maxdc - 1) ? 1 : params->ems_nc + 1;
+		const size_t lds = ((size_t)maxdc * q + (2 * (size_t)layers + 1) * q + (size_t)maxdc * params->ems_nm) * 8 + (size_t)maxdc * params->ems_nm * 4 + 16;
+		const bool special = q == 256 && maxdc == 4 && params->ems_nc >= 1 && (params->ems_nm == 8 || params->ems_nm == 16 || params->ems_nm == 32);
+		if (!special && lds > 160 * 1024)
+			return fail_create(nullptr, NBL_ERR_UNSUPPORTED, "EMS: this (q, check degree, nm, nc) needs more than the 160 KB of LDS one wave can have");
+	}
+	// primitive polynomial recovered from the table: x * x^(p-1) = x^p = poly - q
 	const int poly = q | gf_mul[(size_t)2 * q + (q >> 1)];
 	for (int a = 0; a < q; a++) {
 		int expect = (a << 1);

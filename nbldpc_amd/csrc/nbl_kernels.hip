@@ -591,7 +591,11 @@ hipError_t nbl_launch_cn_ems(const NblGraphDev &g, const NblWork &w, const NblRu
 	const int layers = nbl_ems_layers(g, r.nc);
 	const size_t lds = nbl_ems_lds_bytes(g, r.nm, layers);
 	dim3 grid((unsigned)((long long)r.B * g.M)), block(64);
-	NBL_DISPATCH_Q(g.q, cn_ems_kernel<QQ><<<grid, block, lds, st>>>(g, w, r, layers))
+	if (lds > 160 * 1024) return hipErrorInvalidValue; // (nbl_create refuses such shapes)
+	NBL_DISPATCH_Q(g.q, {
+		if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)cn_ems_kernel<QQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		cn_ems_kernel<QQ><<<grid, block, lds, st>>>(g, w, r, layers);
+	})
 	return hipGetLastError();
 }
 

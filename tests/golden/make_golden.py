@@ -67,7 +67,22 @@ SETS = {
                                 constellation="GRAY_256QAM", random_msg=0), 10.0, 2, [1, 2, 3], [1, 2], [0]),
 }
 
+# Deep sets: several reference processes (one lane each, seeds seed0 + k) whose frames are concatenated -- the reference's BP costs
+# ~2.5 s per iteration per codeword at -O0, so the frames are spread over the cores.  name -> (build, profile, EbN0, processes,
+# frames per process, iters, state_iters of process 0 / frame 0)
+DEEP_SETS = {
+    # cfg 5 through a waterfall trajectory: 16 frames at 2.8 dB (most need 10-40 iterations, some never converge), outputs after
+    # 10 and 30 iterations, full message state after 10 iterations for one frame
+    "cfg5_bp_c512_deep": ("O0", dict(gfq=256, code=C512_256, method=1, max_iter=100, parallel=1, nqam=256,
+                                     constellation="GRAY_256QAM", random_msg=0), 2.8, 8, 2, [10, 30], [10]),
+}
+
 FER_SETS = {
+    # cfg 5: 32 frames at 3 dB (waterfall) and at 4 dB (most frames stop within 10 iterations); -O0 build (BP failure path is UB at -O1+)
+    "cfg5_bp_c512_3dB": ("O0", dict(gfq=256, code=C512_256, method=1, max_iter=100, parallel=4, nqam=256, constellation="GRAY_256QAM",
+                                    random_msg=0, snr_begin=3.0, snr_stop=3.0, min_sim_cycle=28)),
+    "cfg5_bp_c512_4dB": ("O0", dict(gfq=256, code=C512_256, method=1, max_iter=100, parallel=4, nqam=256, constellation="GRAY_256QAM",
+                                    random_msg=0, snr_begin=4.0, snr_stop=4.0, min_sim_cycle=28)),
     # BASELINE.md anchors, reproduced here from the compiled reference
     "cfg1_bp_gf16": ("O0", dict(gfq=16, code=U128_16, method=1, max_iter=20, parallel=1, ems_nm=16, ems_nc=2, tems_nc=2,
                                 snr_begin=2.0, snr_stop=3.0, constellation="BPSK", min_err_frame=20, min_sim_cycle=200)),
@@ -114,6 +129,43 @@ def run_set(name):
           f"({time.time() - t0:.1f}s, {os.path.getsize(os.path.join(GOLD, name + '.npz')) / 1e3:.0f} kB)")
 
 
+def run_deep(name):
+    build, kw, ebn0, procs, frames, iters, st_iters = DEEP_SETS[name]
+    tmps, ps = [], []
+    t0 = time.time()
+    for k in range(procs):
+        pk, code, cons = resolve(dict(kw, seed=173 + 7 * k))
+        tmp = tempfile.mkdtemp(prefix="golden_")
+        prof = os.path.join(tmp, "profile.txt")
+        open(prof, "w").write(profile_text(**pk))
+        ps.append(subprocess.Popen([os.path.join(ROOT, "oracle", "_ref", f"ref_driver_{build}"), "dump", prof, tmp, repr(ebn0),
+                                    str(frames), ",".join(map(str, iters)), ",".join(map(str, st_iters)) if k == 0 else ""], cwd=RUN,
+                                   stderr=subprocess.DEVNULL))
+        tmps.append(tmp)
+    for p_ in ps:
+        assert p_.wait() == 0
+    parts = [{k[:-4]: np.load(os.path.join(t, k)) for k in os.listdir(t) if k.endswith(".npy")} for t in tmps]
+    arrs = {}
+    for k in ("L_ch", "tx_code", "tx_msg"):
+        arrs[k] = np.concatenate([p_[k] for p_ in parts], axis=0)
+    for k in ("out", "ret", "syn_ok"):
+        arrs[k] = np.concatenate([p_[k] for p_ in parts], axis=1)
+    arrs["sigma"] = parts[0]["sigma"]
+    arrs["iters"] = parts[0]["iters"]
+    arrs["state_iters"] = parts[0]["state_iters"]
+    for k in ("st_post", "st_v2c", "st_c2v"):
+        arrs[k] = parts[0][k]
+    arrs["state_lanes"] = np.array([0], dtype=np.int32)
+    meta = dict(profile=dict(kw), code=code, constellation=cons, ebn0=ebn0, frames=frames * procs, build=build,
+                seeds=[173 + 7 * k for k in range(procs)],
+                reference_flags="-std=c++14 -O2 (NBLDPC.cpp at -%s) -ffp-contract=off, g++ 11.4, x86-64" % build)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), meta=json.dumps(meta), **arrs)
+    for t in tmps:
+        shutil.rmtree(t)
+    print(f"{name}: B={arrs['L_ch'].shape[0]} ret={arrs['ret'].tolist()} syn_ok={arrs['syn_ok'].tolist()} "
+          f"({time.time() - t0:.1f}s, {os.path.getsize(os.path.join(GOLD, name + '.npz')) / 1e3:.0f} kB)")
+
+
 def run_fer(names):
     path = os.path.join(GOLD, "fer_anchors.json")
     anchors = json.load(open(path)) if os.path.exists(path) else {}
@@ -137,10 +189,12 @@ def run_fer(names):
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (list(SETS) + ["fer:" + k for k in FER_SETS])
+    want = sys.argv[1:] or (list(SETS) + list(DEEP_SETS) + ["fer:" + k for k in FER_SETS])
     for w in want:
         if w.startswith("fer:"):
             run_fer([w[4:]])
+        elif w in DEEP_SETS:
+            run_deep(w)
         else:
             run_set(w)
 

@@ -75,3 +75,29 @@ def test_no_device_means_error_not_fallback():
     with pytest.raises(nb.NblError) as e:
         _create(code, method=nb.METHOD_EMS, max_iter=5, ems_nm=8)
     assert e.value.status == -3 and "no CPU decode path" in str(e.value)
+
+
+def _ring_code(q, M, dc):
+    """A synthetic (2, dc)-regular graph (dc even): M checks, N = M dc / 2 variables; variable n joins checks n % M and
+    (n % M + 1 + n // M) % M -- two different checks, every check gets dc / 2 variables from each rule."""
+    assert dc % 2 == 0 and M > dc // 2
+    N = M * dc // 2
+    chk_rows = [[] for _ in range(M)]
+    var_rows = [[] for _ in range(N)]
+    for n in range(N):
+        for m in (n % M, (n % M + 1 + n // M) % M):
+            h = 1 + (7 * n + 3 * m) % (q - 1)
+            var_rows[n].append((m + 1, h))
+            chk_rows[m].append((n + 1, h))
+    return nb.Code(spec=dict(N=N, M=M, q=q, var_rows=var_rows, chk_rows=chk_rows))
+
+
+def test_create_refuses_shapes_the_kernels_cannot_run():
+    """Limits of the kernels are refused by nbl_create with NBL_ERR_UNSUPPORTED and a message, not at the first decode."""
+    code = _ring_code(256, 8, 6)                       # GF(256), check degree 6: 8 * 6 > 32
+    assert code.chk_deg.max() == 6 and code.var_deg.max() == 2
+    with pytest.raises(nb.NblError) as e:
+        _create(code, method=nb.METHOD_TEMS, max_iter=5, tems_nr=2, tems_nc=2)
+    assert e.value.status == -2 and "must not exceed 32" in str(e.value)
+    # (EMS at the largest supported shape -- GF(256), check degree 8, nm = q, nc = 6: 71 KB of LDS -- is accepted and run by
+    #  tests/test_gpu_parity.py::test_generic_ems_beyond_64k_lds)

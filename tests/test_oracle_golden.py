@@ -68,6 +68,18 @@ def test_literal_bit_exact_bp_gf256(oracle):
     assert np.array_equal(c2v, g["st_c2v"][0, 0]) and np.array_equal(v2c, g["st_v2c"][0, 0]) and np.array_equal(post, g["st_post"][0, 0])
 
 
+def test_literal_bit_exact_bp_gf256_deep(oracle):
+    """Ten iterations into a waterfall trajectory (2.8 dB, 256-QAM; the frame has not converged yet): message state, hard decision
+    and zero-syndrome flag of the oracle's literal BP equal the compiled reference's bit for bit."""
+    g, meta = load_golden("cfg5_bp_c512_deep")
+    assert int(g["state_iters"][0]) == 10 and int(g["iters"][0]) == 10 and g["syn_ok"][0, 0] == 0
+    dec = _mk(oracle, meta, 10, oracle.LITERAL)
+    r, out, _ = dec.decode(g["L_ch"][0])
+    assert np.array_equal(out, g["out"][0, 0]) and r == g["syn_ok"][0, 0]
+    post, v2c, c2v = dec.state()
+    assert np.array_equal(c2v, g["st_c2v"][0, 0]) and np.array_equal(v2c, g["st_v2c"][0, 0]) and np.array_equal(post, g["st_post"][0, 0])
+
+
 @pytest.mark.parametrize("name", [s for s in FAST_SETS if s != "cfg1_bp_gf16"])
 def test_canonical_matches_reference_decisions(oracle, name):
     _check_decisions(oracle, name, oracle.CANONICAL, max_frames=8)

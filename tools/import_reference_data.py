@@ -9,7 +9,7 @@ These are input data (code definitions and modulation points), not source code: 
 formats are re-emitted on demand by nbldpc_amd.datafiles (write_code_file / write_constellation_file) so the
 drop-in harness can read them exactly like the reference does (NBLDPC.cpp:147-205, Comm.cpp:113-126).
 GF arithmetic tables are NOT imported: they are generated from the primitive polynomial and only compared
-against the reference's Arith.Table files in tests/test_gf_tables.py.
+against the reference's Arith.Table files in tests/test_host_data.py.
 """
 import glob
 import json
