@@ -112,6 +112,20 @@ nbl_status nbl_set_demodulator(nbl_decoder *dec, const nbl_demod_desc *demod);
 nbl_status nbl_decode_batch_samples(nbl_decoder *dec, const double *rx, double sigma, int32_t B, int32_t *out_sym,
                                     uint8_t *converged, int32_t *iters);
 
+/* ---- AWGN channel on the device ------------------------------------------------------------------------
+ * Replaces CComm::Channel_AWGN (Comm.cpp:328-337) and its noise source CRand (Rand.cpp:17-37) for a batch of lanes: the received
+ * samples RX = TX + Rand_Norm(0, sigma) are formed in HBM with the reference's generator and expression order, bit for bit (the
+ * log / cos values whose rounding a GPU cannot settle are evaluated by the host's libm inside the call), then demodulated
+ * (nbl_set_demodulator must have been called, WITH the constellation points, also for BPSK) and decoded.
+ *   tx_index   HOST [B][L] uint8   index into the constellation of every transmitted symbol (CComm::Modulate, Comm.cpp:310-325)
+ *   lane_state HOST [B][3] uint32  IX, IY, IZ of each lane's CRand before the frame's first draw
+ * The frame consumes 4 L uniform draws per lane (real and imaginary part of every symbol, two draws each); the caller moves
+ * its copy of each lane's generator on with nbl_rand_advance(state, 4 L). */
+nbl_status nbl_decode_batch_noise(nbl_decoder *dec, const uint8_t *tx_index, const uint32_t *lane_state, double sigma, int32_t B,
+                                  int32_t *out_sym, uint8_t *converged, int32_t *iters);
+/* state <- state after `draws` calls of CRand::Rand_Uniform (Rand.cpp:17-28); pure host arithmetic */
+void nbl_rand_advance(uint32_t state[3], uint64_t draws);
+
 /* Message state of codeword b after the last decode call (host buffers, any may be NULL):
  * post [N][q-1], v2c [E][q-1], c2v [E][q-1], edges in variable-major order.  For parity tests.
  * post and c2v are the reference's members at return.  v2c differs for a codeword that CONVERGED at iteration k >= 2: the

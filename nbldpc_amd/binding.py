@@ -17,7 +17,7 @@ METHOD_BP, METHOD_EMS, METHOD_TEMS = 1, 2, 4
 
 # every symbol include/nbldpc.h declares
 EXPORTS = ("nbl_abi_version", "nbl_create", "nbl_destroy", "nbl_decode_batch", "nbl_decode_batch_device",
-           "nbl_set_demodulator", "nbl_decode_batch_samples",
+           "nbl_set_demodulator", "nbl_decode_batch_samples", "nbl_decode_batch_noise", "nbl_rand_advance",
            "nbl_read_state", "nbl_set_record_state", "nbl_set_profiling", "nbl_last_timing", "nbl_last_error",
            "nbl_workspace_bytes")
 
@@ -167,6 +167,29 @@ class Decoder:
         self.lib.nbl_decode_batch_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         self._chk(self.lib.nbl_decode_batch_samples(self.h, rx.ctypes.data, sigma, B, out.ctypes.data, conv.ctypes.data, iters.ctypes.data))
         return out, conv, iters
+
+    def decode_noise(self, tx_index, lane_state, sigma):
+        """tx_index [B][L] uint8, lane_state [B][3] uint32 (CRand state before the frame): channel + demodulator + decode on the device"""
+        tx_index = np.ascontiguousarray(tx_index, dtype=np.uint8)
+        lane_state = np.ascontiguousarray(lane_state, dtype=np.uint32)
+        B = tx_index.shape[0]
+        out = np.zeros((B, self.code.N), dtype=np.int32)
+        conv = np.zeros(B, dtype=np.uint8)
+        iters = np.zeros(B, dtype=np.int32)
+        self.lib.nbl_decode_batch_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.nbl_decode_batch_noise(self.h, tx_index.ctypes.data, lane_state.ctypes.data, sigma, B, out.ctypes.data, conv.ctypes.data, iters.ctypes.data))
+        return out, conv, iters
+
+    def channel(self, tx_index, lane_state, sigma):
+        """diagnostic: the received samples [B][L][2] the device-side channel forms, and the fraction of log / cos values the host's libm settled"""
+        tx_index = np.ascontiguousarray(tx_index, dtype=np.uint8)
+        lane_state = np.ascontiguousarray(lane_state, dtype=np.uint32)
+        B, L = tx_index.shape
+        rx = np.zeros((B, L, 2))
+        frac = C.c_double(0)
+        self.lib.nbl_debug_channel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.POINTER(C.c_double)]
+        self._chk(self.lib.nbl_debug_channel(self.h, tx_index.ctypes.data, lane_state.ctypes.data, sigma, B, rx.ctypes.data, C.byref(frac)))
+        return rx, frac.value
 
     def read_lch(self, b):
         L = np.zeros((self.code.N, self.code.q - 1))

@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/nbldpc.h"
 #include "nbl_kernels.h"
@@ -38,6 +40,19 @@ struct nbl_decoder {
 	int *d_src = nullptr;
 	double *d_rx = nullptr;
 	size_t d_rx_cap = 0;
+	// device-side AWGN channel (nbl_decode_batch_noise)
+	std::vector<double> h_cons;  // constellation as given to nbl_set_demodulator
+	uint32_t *d_jump = nullptr;  // [3][L] A^(4 s) mod m of the three generators
+	uint32_t *d_state = nullptr; // [cap][3]
+	uint8_t *d_txi = nullptr;    // [cap][L]
+	double *d_fn = nullptr;      // [cap][L][2][2]: log(1 - u1), cos(2 pi u2) of every normal draw
+	uint32_t *d_fidx = nullptr;  // uncertain values: index into d_fn, argument, host-evaluated value
+	double *d_farg = nullptr, *d_fval = nullptr;
+	unsigned *d_fcount = nullptr;
+	uint32_t *h_fidx = nullptr;  // pinned host mirrors
+	double *h_farg = nullptr, *h_fval = nullptr;
+	size_t noise_cap = 0, flag_cap = 0;
+	double last_flag_frac = 0.0;
 	int force_generic = 0;      // debug: 1 = always the generic kernels, 2 = specialised kernels but no VN/CN fusion
 	bool profiling = false;
 	hipEvent_t ev[2] = {nullptr, nullptr};
@@ -276,6 +291,10 @@ extern "C" void nbl_destroy(nbl_decoder *d)
 	if (d->d_src) (void)hipFree(d->d_src);
 	if (d->d_cons) (void)hipFree(d->d_cons);
 	if (d->d_rx) (void)hipFree(d->d_rx);
+	for (void *p : {(void *)d->d_jump, (void *)d->d_state, (void *)d->d_txi, (void *)d->d_fn, (void *)d->d_fidx, (void *)d->d_farg, (void *)d->d_fval, (void *)d->d_fcount})
+		if (p) (void)hipFree(p);
+	for (void *p : {(void *)d->h_fidx, (void *)d->h_farg, (void *)d->h_fval})
+		if (p) (void)hipHostFree(p);
 	for (auto &e : d->ev)
 		if (e) (void)hipEventDestroy(e);
 	for (auto &e : d->pev) (void)hipEventDestroy(e);
@@ -497,6 +516,13 @@ extern "C" nbl_status nbl_set_demodulator(nbl_decoder *d, const nbl_demod_desc *
 		HIP_TRY(d, hipMalloc((void **)&d->d_cons, (size_t)q * 16));
 		HIP_TRY(d, hipMemcpy(d->d_cons, dm->constellation, (size_t)q * 16, hipMemcpyHostToDevice));
 	}
+	d->h_cons.clear();
+	if (dm->constellation) d->h_cons.assign(dm->constellation, dm->constellation + (size_t)2 * dm->mod_order);
+	if (!d->d_cons && dm->constellation) { // BPSK: the demodulator does not need the points, the channel does
+		HIP_TRY(d, hipMalloc((void **)&d->d_cons, (size_t)dm->mod_order * 16));
+		HIP_TRY(d, hipMemcpy(d->d_cons, dm->constellation, (size_t)dm->mod_order * 16, hipMemcpyHostToDevice));
+	}
+	if (d->d_jump) { (void)hipFree(d->d_jump); d->d_jump = nullptr; }
 	d->dm_order = dm->mod_order;
 	d->dm_L = dm->n_mod_sym;
 	return NBL_OK;
@@ -527,6 +553,150 @@ extern "C" nbl_status nbl_decode_batch_samples(nbl_decoder *d, const double *rx,
 	if (converged) HIP_TRY(d, hipMemcpyAsync(converged, d->w.done, (size_t)B, hipMemcpyDeviceToHost, d->stream));
 	if (iters) HIP_TRY(d, hipMemcpyAsync(iters, d->w.iters, (size_t)B * 4, hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(d, hipStreamSynchronize(d->stream));
+	return NBL_OK;
+}
+
+
+// ---- AWGN channel + CRand on the device ------------------------------------------------------------------
+
+static uint32_t mod_pow(uint32_t a, uint64_t k, uint32_t m)
+{
+	uint64_t r = 1 % m, x = a % m;
+	for (; k; k >>= 1) {
+		if (k & 1) r = r * x % m;
+		x = x * x % m;
+	}
+	return (uint32_t)r;
+}
+
+extern "C" void nbl_rand_advance(uint32_t state[3], uint64_t draws)
+{
+	state[0] = (uint32_t)((uint64_t)(state[0] % 61967u) * mod_pow(249, draws, 61967) % 61967u);
+	state[1] = (uint32_t)((uint64_t)(state[1] % 63443u) * mod_pow(251, draws, 63443) % 63443u);
+	state[2] = (uint32_t)((uint64_t)(state[2] % 63599u) * mod_pow(252, draws, 63599) % 63599u);
+}
+
+static nbl_status ensure_noise(nbl_decoder *d, int B)
+{
+	const size_t L = d->dm_L;
+	if (!d->d_jump) {
+		std::vector<uint32_t> jump(3 * L);
+		const uint32_t A[3] = {249, 251, 252}, M[3] = {61967, 63443, 63599};
+		for (int g = 0; g < 3; g++) {
+			uint64_t x = 1;
+			const uint32_t a4 = mod_pow(A[g], 4, M[g]);
+			for (size_t s = 0; s < L; s++) { jump[g * L + s] = (uint32_t)x; x = x * a4 % M[g]; }
+		}
+		HIP_TRY(d, hipMalloc((void **)&d->d_jump, jump.size() * 4));
+		HIP_TRY(d, hipMemcpy(d->d_jump, jump.data(), jump.size() * 4, hipMemcpyHostToDevice));
+	}
+	if ((size_t)B <= d->noise_cap) return NBL_OK;
+	for (void *p : {(void *)d->d_state, (void *)d->d_txi, (void *)d->d_fn, (void *)d->d_fidx, (void *)d->d_farg, (void *)d->d_fval})
+		if (p) (void)hipFree(p);
+	for (void *p : {(void *)d->h_fidx, (void *)d->h_farg, (void *)d->h_fval})
+		if (p) (void)hipHostFree(p);
+	d->d_state = nullptr; d->d_txi = nullptr; d->d_fn = nullptr; d->d_fidx = nullptr; d->d_farg = d->d_fval = nullptr;
+	d->h_fidx = nullptr; d->h_farg = d->h_fval = nullptr;
+	d->noise_cap = 0;
+	const size_t nval = (size_t)B * L * 4; // two functions per normal draw, two draws per symbol
+	if (nval > 0xffffffffull) { d->err = "nbl_decode_batch_noise: batch * symbols too large for 32-bit value indices"; return NBL_ERR_ARG; }
+	// about 16 % of the values are uncertain (5 % of the logarithms, 11 % of the cosines); room for 30 %
+	const size_t cap = nval * 3 / 10 + 4096;
+	HIP_TRY(d, hipMalloc((void **)&d->d_state, (size_t)B * 12));
+	HIP_TRY(d, hipMalloc((void **)&d->d_txi, (size_t)B * L));
+	HIP_TRY(d, hipMalloc((void **)&d->d_fn, nval * 8));
+	HIP_TRY(d, hipMalloc((void **)&d->d_fidx, cap * 4));
+	HIP_TRY(d, hipMalloc((void **)&d->d_farg, cap * 8));
+	HIP_TRY(d, hipMalloc((void **)&d->d_fval, cap * 8));
+	if (!d->d_fcount) HIP_TRY(d, hipMalloc((void **)&d->d_fcount, 16));
+	HIP_TRY(d, hipHostMalloc((void **)&d->h_fidx, cap * 4, hipHostMallocDefault));
+	HIP_TRY(d, hipHostMalloc((void **)&d->h_farg, cap * 8, hipHostMallocDefault));
+	HIP_TRY(d, hipHostMalloc((void **)&d->h_fval, cap * 8, hipHostMallocDefault));
+	d->noise_cap = B;
+	d->flag_cap = cap;
+	return NBL_OK;
+}
+
+// Forms RX = TX + noise in d->d_rx for B lanes (the three kernels of nbl_noise.hip with the host's libm in between).
+static nbl_status run_channel(nbl_decoder *d, const uint8_t *tx_index, const uint32_t *lane_state, double sigma, int B)
+{
+	if (!d->dm_order) { d->err = "nbl_set_demodulator has not been called"; return NBL_ERR_ARG; }
+	if (d->h_cons.empty() || !d->d_cons) { d->err = "the channel needs the constellation points (nbl_demod_desc.constellation), also for BPSK"; return NBL_ERR_ARG; }
+	nbl_status s = ensure_noise(d, B);
+	if (s) return s;
+	const size_t L = d->dm_L;
+	const size_t bytes = (size_t)B * L * 16;
+	if (bytes > d->d_rx_cap) {
+		if (d->d_rx) (void)hipFree(d->d_rx);
+		d->d_rx = nullptr;
+		HIP_TRY(d, hipMalloc((void **)&d->d_rx, bytes));
+		d->d_rx_cap = bytes;
+	}
+	hipStream_t st = d->stream;
+	HIP_TRY(d, hipMemcpyAsync(d->d_state, lane_state, (size_t)B * 12, hipMemcpyHostToDevice, st));
+	HIP_TRY(d, hipMemcpyAsync(d->d_txi, tx_index, (size_t)B * L, hipMemcpyHostToDevice, st));
+	HIP_TRY(d, hipMemsetAsync(d->d_fcount, 0, 4, st));
+	HIP_TRY(d, nbl_launch_noise_gen(d->d_state, d->d_jump, (int)L, B, d->d_fn, d->d_fidx, d->d_farg, d->d_fcount, (unsigned)d->flag_cap, st));
+	unsigned nflag = 0;
+	HIP_TRY(d, hipMemcpyAsync(&nflag, d->d_fcount, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(d, hipStreamSynchronize(st));
+	if (nflag > d->flag_cap) { d->err = "nbl_decode_batch_noise: more uncertain values than the list holds (30 % of all)"; return NBL_ERR_NOMEM; }
+	d->last_flag_frac = (double)nflag / ((double)B * L * 4);
+	if (nflag) {
+		HIP_TRY(d, hipMemcpyAsync(d->h_fidx, d->d_fidx, (size_t)nflag * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(d, hipMemcpyAsync(d->h_farg, d->d_farg, (size_t)nflag * 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(d, hipStreamSynchronize(st));
+		// the host's own libm decides the uncertain values: log(1 - u1) (even index) or cos(2 pi u2) (odd index), Rand.cpp:35
+		int T = (int)std::thread::hardware_concurrency();
+		if (const char *e = getenv("NBL_HOST_THREADS")) T = atoi(e);
+		if (T > 16) T = 16;
+		if (T < 1 || nflag < 4096) T = 1;
+		auto work = [&](unsigned lo, unsigned hi) {
+			for (unsigned k = lo; k < hi; k++) d->h_fval[k] = (d->h_fidx[k] & 1u) ? std::cos(d->h_farg[k]) : std::log(d->h_farg[k]);
+		};
+		if (T == 1) work(0, nflag);
+		else {
+			std::vector<std::thread> th;
+			for (int t = 0; t < T; t++) th.emplace_back(work, (unsigned)((uint64_t)nflag * t / T), (unsigned)((uint64_t)nflag * (t + 1) / T));
+			for (auto &x : th) x.join();
+		}
+		HIP_TRY(d, hipMemcpyAsync(d->d_fval, d->h_fval, (size_t)nflag * 8, hipMemcpyHostToDevice, st));
+		HIP_TRY(d, nbl_launch_noise_patch(d->d_fn, d->d_fidx, d->d_fval, nflag, st));
+	}
+	HIP_TRY(d, nbl_launch_noise_finish(d->d_fn, d->d_txi, d->d_cons, sigma, (int)L, B, d->d_rx, st));
+	return NBL_OK;
+}
+
+extern "C" nbl_status nbl_decode_batch_noise(nbl_decoder *d, const uint8_t *tx_index, const uint32_t *lane_state, double sigma, int32_t B,
+                                             int32_t *out_sym, uint8_t *converged, int32_t *iters)
+{
+	if (!d || !tx_index || !lane_state || !out_sym || B < 0 || !(sigma > 0)) return NBL_ERR_ARG;
+	if (B == 0) return NBL_OK;
+	HIP_TRY(d, hipSetDevice(d->device));
+	nbl_status s = ensure_workspace(d, B);
+	if (s) return s;
+	if ((s = run_channel(d, tx_index, lane_state, sigma, B))) return s;
+	HIP_TRY(d, nbl_launch_demod(d->d_rx, d->dm_L, sigma, d->dm_order, d->d_cons, d->d_src, d->g, d->w, B, d->stream));
+	if ((s = run_iterations(d, nullptr, B, d->stream))) return s;
+	HIP_TRY(d, hipMemcpyAsync(out_sym, d->w.out, (size_t)B * d->g.N * 4, hipMemcpyDeviceToHost, d->stream));
+	if (converged) HIP_TRY(d, hipMemcpyAsync(converged, d->w.done, (size_t)B, hipMemcpyDeviceToHost, d->stream));
+	if (iters) HIP_TRY(d, hipMemcpyAsync(iters, d->w.iters, (size_t)B * 4, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(d, hipStreamSynchronize(d->stream));
+	return NBL_OK;
+}
+
+// Diagnostic only (not part of include/nbldpc.h): run the channel alone and return the received samples [B][L][2] and the
+// fraction of log / cos values that went to the host's libm.
+extern "C" nbl_status nbl_debug_channel(nbl_decoder *d, const uint8_t *tx_index, const uint32_t *lane_state, double sigma, int32_t B,
+                                        double *rx_out, double *flag_frac)
+{
+	if (!d || !tx_index || !lane_state || !rx_out || B <= 0) return NBL_ERR_ARG;
+	HIP_TRY(d, hipSetDevice(d->device));
+	nbl_status s = run_channel(d, tx_index, lane_state, sigma, B);
+	if (s) return s;
+	HIP_TRY(d, hipMemcpyAsync(rx_out, d->d_rx, (size_t)B * d->dm_L * 16, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(d, hipStreamSynchronize(d->stream));
+	if (flag_frac) *flag_frac = d->last_flag_frac;
 	return NBL_OK;
 }
 

@@ -33,3 +33,9 @@ hipError_t nbl_launch_cn_tems256(const NblGraphDev &g, const NblWork &w, const N
 // log-QSPA check node for GF(256), check degree 4 (nbl_cn_bp256.hip)
 bool nbl_bp256_applicable(const NblGraphDev &g, bool all_dc4);
 hipError_t nbl_launch_cn_bp256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st);
+
+// AWGN channel + CRand on the device (nbl_noise.hip)
+hipError_t nbl_launch_noise_gen(const uint32_t *state, const uint32_t *jump, int L, int B, double *fn, uint32_t *flag_idx, double *flag_arg,
+                                unsigned *flag_count, unsigned cap, hipStream_t st);
+hipError_t nbl_launch_noise_patch(double *fn, const uint32_t *flag_idx, const double *val, unsigned n, hipStream_t st);
+hipError_t nbl_launch_noise_finish(const double *fn, const uint8_t *tx_index, const double *cons, double sigma, int L, int B, double *rx, hipStream_t st);

@@ -53,6 +53,57 @@ int nblh_frontend(const char *profile, double ebn0, int frames, double *L_ch, in
 	return 0;
 }
 
+// Host link chain up to and including Channel_AWGN for `frames` cycles (no GPU): received samples rx [frames*P][L][2], the
+// constellation index of every transmitted symbol tx_index [frames*P][L] and each lane's generator state in front of each
+// frame state [frames*P][3] -- what the device-side channel is given, and what it must reproduce.
+int nblh_channel(const char *profile, double ebn0, int frames, double *rx, unsigned char *tx_index, unsigned int *state, double *sigma_out)
+{
+	CSimulation sim;
+	if (sim.Initial(profile) != 0) return -1;
+	sim.EbN0 = ebn0;
+	CLink link;
+	link.sim = sim;
+	CNBLDPC &code = link.code;
+	if (!code.Initial(link.sim, -1)) return -2;
+	const int P = sim.parallel;
+	std::vector<std::unique_ptr<CComm>> lanes;
+	for (int i = 0; i < P; i++) {
+		lanes.emplace_back(new CComm());
+		if (!lanes.back()->Initial(link.sim, i, &code)) return -3;
+		lanes.back()->SetEbN0(link.sim, i);
+	}
+	if (sigma_out) *sigma_out = lanes[0]->sigma_n;
+	const int L = lanes[0]->MOD_SYM_LEN;
+	auto work = [&](int lo, int hi) {
+		for (int i = lo; i < hi; i++) {
+			CComm &c = *lanes[i];
+			for (int f = 0; f < frames; f++) {
+				const size_t b = (size_t)f * P + i;
+				state[b * 3 + 0] = (unsigned int)(c.Rand.IX % 61967ul);
+				state[b * 3 + 1] = (unsigned int)(c.Rand.IY % 63443ul);
+				state[b * 3 + 2] = (unsigned int)(c.Rand.IZ % 63599ul);
+				c.FrontEndToChannel();
+				for (int s = 0; s < L; s++) {
+					rx[(b * L + s) * 2] = c.RX_MOD_SYM[s].Real;
+					rx[(b * L + s) * 2 + 1] = c.RX_MOD_SYM[s].Image;
+					tx_index[b * L + s] = c.TX_MOD_IDX[s];
+				}
+			}
+		}
+	};
+	int T = (int)std::thread::hardware_concurrency();
+	if (const char *e = getenv("NBL_HOST_THREADS")) T = atoi(e);
+	if (T > 16) T = 16;
+	if (T > P) T = P;
+	if (T <= 1) work(0, P);
+	else {
+		std::vector<std::thread> th;
+		for (int t = 0; t < T; t++) th.emplace_back(work, (int)((long long)P * t / T), (int)((long long)P * (t + 1) / T));
+		for (auto &x : th) x.join();
+	}
+	return L;
+}
+
 // Full simulation of one profile on the GPU; per Eb/N0 point: EbN0, errFrame, errSym, errBit, U_errFrame, frames, BER, SER, FER.
 int nblh_simulate(const char *profile, int device, double *rows, int max_rows)
 {

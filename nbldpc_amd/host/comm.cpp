@@ -77,6 +77,7 @@ bool CComm::Initial(CSimulation &sim, int lane, CNBLDPC *shared)
 	TX_MOD_BIT.assign(MOD_BIT_LEN, 0);
 	TX_MOD_SYM.assign(MOD_SYM_LEN, CComplex());
 	RX_MOD_SYM.assign(MOD_SYM_LEN, CComplex());
+	TX_MOD_IDX.assign(MOD_SYM_LEN, 0);
 	RX_LLR_BIT.assign(CODE_BIT_LEN, 0.0);
 	RX_LLR_SYM.assign((size_t)CODE_SYM_LEN * (GFq - 1), 0.0);
 	RX_DECODE_SYM.assign(CODE_SYM_LEN, 0);
@@ -111,6 +112,19 @@ int CComm::FrontEndToChannel()
 	Puncture();
 	Modulate();
 	return Channel_AWGN();
+}
+
+int CComm::FrontEndToModulate(unsigned int state_out[3])
+{
+	GenerateMessage();
+	Encode();
+	Puncture();
+	Modulate();
+	state_out[0] = (unsigned int)(Rand.IX % 61967ul);
+	state_out[1] = (unsigned int)(Rand.IY % 63443ul);
+	state_out[2] = (unsigned int)(Rand.IZ % 63599ul);
+	Rand.Skip(4ul * (unsigned long)MOD_SYM_LEN);
+	return 0;
 }
 
 // the index bookkeeping of Demodulate (Comm.cpp:348-357 / :384-396) as a table: -1 marks a punctured position
@@ -281,6 +295,7 @@ int CComm::Modulate() // Comm.cpp:310-325: MSB first (the reverse of Encode's un
 		int idx = 0;
 		for (int k = 0; k < MOD_BIT_PER_SYM; k++) idx += TX_MOD_BIT[s * MOD_BIT_PER_SYM + k] << (MOD_BIT_PER_SYM - 1 - k);
 		TX_MOD_SYM[s] = CONSTELLATION[idx];
+		TX_MOD_IDX[s] = (unsigned char)idx;
 	}
 	return 0;
 }

@@ -26,6 +26,7 @@ public:
 	std::vector<int> TX_MSG_BIT_beforeCRC, TX_MSG_BIT, TX_MSG_SYM, TX_CODE_SYM, TX_CODE_BIT, PUN_SYM, PUN_BIT, TX_MOD_BIT;
 	std::vector<int> RX_DECODE_SYM, RX_DECODE_BIT, RX_MSG_SYM, RX_MSG_BIT;
 	std::vector<CComplex> CONSTELLATION, TX_MOD_SYM, RX_MOD_SYM;
+	std::vector<unsigned char> TX_MOD_IDX; // constellation index of every transmitted symbol (what Modulate looked up)
 	std::vector<double> RX_LLR_BIT;
 	std::vector<double> RX_LLR_SYM; // [CODE_SYM_LEN][GFq-1], row-major (the reference's double**)
 	bool DecodeCorrect = false;
@@ -34,6 +35,9 @@ public:
 	double SetEbN0(CSimulation &sim, int parallel_order);
 	int FrontEnd();
 	int FrontEndToChannel(); // everything up to Channel_AWGN: the demodulator runs on the device
+	// everything up to Modulate: channel and demodulator run on the device.  The lane's generator state in front of the frame is
+	// returned and the generator is moved past the 4 * MOD_SYM_LEN uniform draws Channel_AWGN would have made (Comm.cpp:328-337).
+	int FrontEndToModulate(unsigned int state_out[3]);
 	void DemodSource(std::vector<int> &src) const; // which received sample carries each code bit (BPSK) / code symbol (q-ary)
 	int GenerateMessage();
 	int GenPN();

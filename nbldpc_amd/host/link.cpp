@@ -33,6 +33,8 @@ bool CLink::Initial(const std::string &profile, const std::vector<int> &device_l
 	}
 	const size_t per = (size_t)code.CodeLen * (code.GFq - 1);
 	if (const char *e = getenv("NBL_DEVICE_DEMOD")) device_demod = atoi(e) != 0;
+	if (const char *e = getenv("NBL_DEVICE_NOISE")) device_noise = atoi(e) != 0;
+	if (!device_demod || lanes[0]->CONSTELLATION.size() > 256) device_noise = false;
 	if (const char *e = getenv("NBL_PIPELINE")) pipeline = atoi(e) != 0;
 	if (const char *e = getenv("NBL_HOST_THREADS")) host_threads = atoi(e);
 	else { // 16 threads keep one GPU fed; more GPUs decode more lanes per cycle
@@ -52,7 +54,9 @@ bool CLink::Initial(const std::string &profile, const std::vector<int> &device_l
 			if (x->SetDemodulator(lanes[0]->modOrder, lanes[0]->MOD_SYM_LEN, cons.data(), src.data()) != 0) { error = x->LastError(); return false; }
 	}
 	for (int slot = 0; slot < (pipeline ? 2 : 1); slot++) {
-		rx_batch[slot].assign(device_demod ? (size_t)2 * lanes[0]->MOD_SYM_LEN * sim.parallel : 0, 0.0);
+		rx_batch[slot].assign(device_demod && !device_noise ? (size_t)2 * lanes[0]->MOD_SYM_LEN * sim.parallel : 0, 0.0);
+		txi_batch[slot].assign(device_noise ? (size_t)lanes[0]->MOD_SYM_LEN * sim.parallel : 0, 0);
+		state_batch[slot].assign(device_noise ? (size_t)3 * sim.parallel : 0, 0);
 		L_batch[slot].assign(device_demod ? 0 : per * sim.parallel, 0.0);
 	}
 	out_batch.assign((size_t)code.CodeLen * sim.parallel, 0);
@@ -83,7 +87,10 @@ void CLink::FrontEnds(int slot)
 	const size_t per = (size_t)code.CodeLen * (code.GFq - 1);
 	over_lanes(sim.parallel, host_threads, [&](int lo, int hi) {
 		for (int i = lo; i < hi; i++) {
-			if (device_demod) {
+			if (device_noise) {
+				lanes[i]->FrontEndToModulate(&state_batch[slot][(size_t)3 * i]);
+				memcpy(&txi_batch[slot][(size_t)i * lanes[i]->MOD_SYM_LEN], lanes[i]->TX_MOD_IDX.data(), lanes[i]->MOD_SYM_LEN);
+			} else if (device_demod) {
 				lanes[i]->FrontEndToChannel();
 				const int L = lanes[i]->MOD_SYM_LEN;
 				double *rx = &rx_batch[slot][(size_t)i * L * 2];
@@ -111,7 +118,10 @@ bool CLink::Decode(int slot)
 	auto shard = [&](int gidx) {
 		const int lo = (int)((long long)P * gidx / G), hi = (int)((long long)P * (gidx + 1) / G);
 		CNBLDPC &dec = gidx == 0 ? code : *extra[gidx - 1];
-		if (hi > lo)
+		if (hi > lo && device_noise)
+			rc[gidx] = dec.DecodingBatchNoise(&txi_batch[slot][(size_t)lanes[0]->MOD_SYM_LEN * lo], &state_batch[slot][(size_t)3 * lo], sigma, hi - lo,
+			                                  &out_batch[(size_t)code.CodeLen * lo], &conv[lo], &iters[lo]);
+		else if (hi > lo)
 			rc[gidx] = device_demod
 			    ? dec.DecodingBatchSamples(&rx_batch[slot][rxper * lo], sigma, hi - lo, &out_batch[(size_t)code.CodeLen * lo], &conv[lo], &iters[lo])
 			    : dec.DecodingBatch(&L_batch[slot][per * lo], hi - lo, &out_batch[(size_t)code.CodeLen * lo], &conv[lo], &iters[lo]);

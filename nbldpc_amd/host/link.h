@@ -16,6 +16,10 @@ public:
 	bool device_demod = true;          // ship received samples, demodulate on the GPU (bit-identical L_ch);
 	                                   // NBL_DEVICE_DEMOD=0: build L_ch on the host as the reference's Demodulate does
 	std::vector<double> rx_batch[2];   // [parallel][MOD_SYM_LEN][2]
+	bool device_noise = true;          // AWGN channel + CRand on the GPU as well (bit-identical samples);
+	                                   // NBL_DEVICE_NOISE=0 draws the noise on the host threads.  Needs device_demod.
+	std::vector<unsigned char> txi_batch[2]; // [parallel][MOD_SYM_LEN] constellation indices
+	std::vector<unsigned int> state_batch[2]; // [parallel][3] generator states in front of the frame
 	bool pipeline = true;              // NBL_PIPELINE=0: strictly serial cycles
 	int host_threads = 1;
 	std::vector<int> out_batch, iters;

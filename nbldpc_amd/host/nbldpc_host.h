@@ -39,6 +39,9 @@ public:
 	// device-side demodulation (replaces CComm::Demodulate, Comm.cpp:340-407): rx [B][L][2] received samples
 	int SetDemodulator(int mod_order, int n_mod_sym, const double *constellation, const int *src);
 	int DecodingBatchSamples(const double *rx, double sigma, int B, int *out, uint8_t *converged, int *iters);
+	// device-side channel (replaces CComm::Channel_AWGN + CRand, Comm.cpp:328-337 / Rand.cpp:17-37): tx_index [B][L] constellation
+	// indices, lane_state [B][3] generator states in front of the frame
+	int DecodingBatchNoise(const unsigned char *tx_index, const unsigned int *lane_state, double sigma, int B, int *out, uint8_t *converged, int *iters);
 	const std::string &LastError() const { return error; }
 	nbl_decoder *Handle() const { return dec; }
 

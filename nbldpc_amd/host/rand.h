@@ -18,6 +18,19 @@ public:
 		return t;
 	}
 
+	// the state after n calls of Rand_Uniform: X <- X * A^n mod m for each of the three generators
+	void Skip(unsigned long n)
+	{
+		auto pw = [](unsigned long a, unsigned long k, unsigned long m) {
+			unsigned long r = 1 % m, x = a % m;
+			for (; k; k >>= 1) { if (k & 1) r = r * x % m; x = x * x % m; }
+			return r;
+		};
+		IX = (IX % 61967) * pw(249, n, 61967) % 61967;
+		IY = (IY % 63443) * pw(251, n, 63443) % 63443;
+		IZ = (IZ % 63599) * pw(252, n, 63599) % 63599;
+	}
+
 	double Rand_Norm(double mu, double sigma)
 	{
 		const double u1 = Rand_Uniform();

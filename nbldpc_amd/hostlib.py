@@ -24,6 +24,7 @@ def load():
             pass
         L = C.CDLL(HOST_LIB)
         L.nblh_frontend.argtypes = [C.c_char_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.nblh_channel.argtypes = [C.c_char_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         L.nblh_simulate.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int]
         L.nblh_encode.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
@@ -64,6 +65,20 @@ def frontend(workdir_path, ebn0, frames, N, K, q, P):
     if rc != 0:
         raise RuntimeError(f"nblh_frontend rc={rc}")
     return L, tx, msg, sig.value
+
+
+def channel(workdir_path, ebn0, frames, L, P):
+    """Host link chain up to the AWGN channel: (rx [B][L][2], tx_index [B][L] uint8, state [B][3] uint32, sigma), B = frames * P."""
+    B = frames * P
+    rx = np.zeros((B, L, 2))
+    txi = np.zeros((B, L), dtype=np.uint8)
+    state = np.zeros((B, 3), dtype=np.uint32)
+    sig = C.c_double(0)
+    with workdir(workdir_path):
+        rc = load().nblh_channel(b"NBLDPC.Profile.txt", ebn0, frames, rx.ctypes.data, txi.ctypes.data, state.ctypes.data, C.byref(sig))
+    if rc != L:
+        raise RuntimeError(f"nblh_channel rc={rc} (expected MOD_SYM_LEN {L})")
+    return rx, txi, state, sig.value
 
 
 def simulate(workdir_path, device=0, max_rows=32):

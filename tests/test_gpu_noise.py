@@ -1,0 +1,63 @@
+"""SURVEY 8f row 2 on the GPU: the device-side AWGN channel (CRand + Channel_AWGN, Rand.cpp:17-37, Comm.cpp:328-337) must form
+the received samples of the host chain BIT FOR BIT, on more than 10^7 samples, and the decode behind it must give the host
+path's results."""
+import numpy as np
+import pytest
+
+import nbldpc_amd as nb
+import nbldpc_amd.datafiles as df
+from nbldpc_amd import hostlib
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(tmp_path, code_name, cons, method, P, seed, **kw):
+    c = df.codes()[code_name]
+    q = c["q"]
+    hostlib.prepare_workdir(str(tmp_path), dict(gfq=q, code=code_name, method=method, max_iter=10, parallel=P, nqam=(2 if cons == "BPSK" else q),
+                                                constellation=cons, random_msg=(1 if cons == "BPSK" else 0), seed=seed, **kw), code_name, cons)
+    code = nb.Code(code_name)
+    pts = sorted(df.constellations()[cons])
+    points = np.array([[x[1], x[2]] for x in pts])
+    p = q.bit_length() - 1
+    L = c["N"] * p if cons == "BPSK" else c["N"]
+    return code, points, L, q
+
+
+@pytest.mark.parametrize("code_name,cons,method,P,frames,ebn0,kw", [
+    ("divsalar.UNBLDPC.512.256.GF.256", "BPSK", 2, 5120, 2, 1.0, dict(ems_nm=32, ems_nc=3)),       # 2 x 5120 x 512 x 2 = 1.05e7 samples
+    ("BDS.576.288.GF.64", "GRAY_64QAM", 4, 1024, 3, 3.0, dict(tems_nr=2, tems_nc=3)),
+    ("divsalar.CNBLDPC.512.256.GF.256", "GRAY_256QAM", 1, 512, 2, 4.0, dict()),
+])
+def test_device_channel_bit_identical_to_host_chain(tmp_path, code_name, cons, method, P, frames, ebn0, kw):
+    code, points, L, q = _setup(tmp_path, code_name, cons, method, P, 173, **kw)
+    rx, txi, state, sigma = hostlib.channel(str(tmp_path), ebn0, frames, L, P)
+    dec = nb.Decoder(code, method, 10, **kw)
+    if cons == "BPSK":
+        dec.set_demodulator(2, L, np.arange(L), points)
+    else:
+        dec.set_demodulator(q, L, np.arange(L), points)
+    got, frac = dec.channel(txi, state, sigma)
+    assert got.shape == rx.shape
+    assert np.array_equal(got.view(np.uint64), rx.view(np.uint64)), f"{int((got.view(np.uint64) != rx.view(np.uint64)).sum())} of {rx.size} samples differ"
+    assert 0.06 < frac < 0.12, frac     # share of the log / cos values settled by the host's libm (~5 % of the logs, ~12 % of the cosines)
+    # and the whole call: channel + demodulator + decode on the device == host channel, device demodulator + decode
+    o1, c1, i1 = dec.decode_noise(txi[:256], state[:256], sigma)
+    o2, c2, i2 = dec.decode_samples(rx[:256], sigma)
+    assert np.array_equal(o1, o2) and np.array_equal(c1, c2) and np.array_equal(i1, i2)
+    dec.close()
+
+
+def test_rand_advance_matches_the_lanes(tmp_path):
+    """nbl_rand_advance(state, 4 L) is the state the host chain reaches after a frame"""
+    import ctypes as C
+    code, points, L, q = _setup(tmp_path, "divsalar.UNBLDPC.128.64.GF.256", "BPSK", 2, 64, 4242, ems_nm=16, ems_nc=3)
+    rx, txi, state, sigma = hostlib.channel(str(tmp_path), 2.0, 3, L, 64)
+    lib = nb.load_library()
+    lib.nbl_rand_advance.argtypes = [C.c_void_p, C.c_uint64]
+    lib.nbl_rand_advance.restype = None
+    for lane in (0, 1, 63):
+        st = state[lane].copy()
+        for f in (1, 2):
+            lib.nbl_rand_advance(st.ctypes.data, 4 * L)
+            assert np.array_equal(st, state[f * 64 + lane])
