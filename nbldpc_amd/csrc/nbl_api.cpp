@@ -53,6 +53,13 @@ struct nbl_decoder {
 	double *h_farg = nullptr, *h_fval = nullptr;
 	size_t noise_cap = 0, flag_cap = 0;
 	double last_flag_frac = 0.0;
+	// hipGraph replay of the iteration loop: one executable graph per window of iterations (fixed iterations: the whole loop;
+	// early exit: the `poll_every` iterations between two polls), captured on the decoder's own stream the first time a window is
+	// run with a given set of buffers, replayed on the caller's stream afterwards.  NBL_GRAPH=0 switches it off.
+	struct GraphKey { const void *lin, *lch, *v2c, *c2v, *alt, *post; int B, record, generic, fused; };
+	GraphKey gkey{};
+	std::vector<hipGraphExec_t> gexec; // index = window number
+	bool use_graph = false;            // opt-in (NBL_GRAPH=1): measured gain is nil, see DESIGN.md section 7
 	int force_generic = 0;      // debug: 1 = always the generic kernels, 2 = specialised kernels but no VN/CN fusion
 	bool profiling = false;
 	hipEvent_t ev[2] = {nullptr, nullptr};
@@ -89,8 +96,16 @@ template <typename T> static nbl_status upload(nbl_decoder *d, const std::vector
 	return NBL_OK;
 }
 
+static void drop_graphs(nbl_decoder *d)
+{
+	for (auto &ge : d->gexec)
+		if (ge) (void)hipGraphExecDestroy(ge);
+	d->gexec.clear();
+}
+
 static void free_workspace(nbl_decoder *d)
 {
+	drop_graphs(d);
 	void *ptrs[] = {d->w.Lch, d->w.v2c, d->w.c2v, d->w.post, d->w.dec, d->w.out, d->w.iters, d->w.done, d->d_Lin, d->d_conv8, d->c2v_alt, d->w.edge_dec};
 	d->c2v_alt = nullptr;
 	for (void *p : ptrs)
@@ -244,6 +259,7 @@ extern "C" nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_m
 	d->prm = *params;
 	if (hipSetDevice(device) != hipSuccess) return fail_create(d, NBL_ERR_HIP, "hipSetDevice failed");
 	if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) return fail_create(d, NBL_ERR_HIP, "hipStreamCreate failed");
+	if (const char *e = getenv("NBL_GRAPH")) d->use_graph = atoi(e) != 0;
 	d->g.N = N; d->g.M = M; d->g.E = E; d->g.q = q; d->g.p = p; d->g.poly = poly; d->g.maxdc = maxdc; d->g.maxdv = maxdv;
 	std::vector<uint8_t> mul8((size_t)q * q);
 	for (size_t i = 0; i < mul8.size(); i++) mul8[i] = (uint8_t)gf_mul[i];
@@ -286,6 +302,7 @@ extern "C" void nbl_destroy(nbl_decoder *d)
 	if (!d) return;
 	if (d->device >= 0) (void)hipSetDevice(d->device);
 	if (d->stream) { (void)hipStreamSynchronize(d->stream); }
+	(void)hipDeviceSynchronize(); // graphs may still be running on a caller's stream
 	free_workspace(d);
 	for (void *p : d->graph_allocs) (void)hipFree(p);
 	if (d->d_src) (void)hipFree(d->d_src);
@@ -315,6 +332,15 @@ extern "C" nbl_status nbl_debug_force_generic(nbl_decoder *d, int32_t on)
 	if (!d) return NBL_ERR_ARG;
 	d->force_generic = on;
 	return NBL_OK;
+}
+
+// Diagnostic only (not part of include/nbldpc.h): number of iteration windows currently held as executable hipGraphs
+extern "C" int32_t nbl_debug_graph_windows(nbl_decoder *d)
+{
+	int n = 0;
+	if (d)
+		for (auto &ge : d->gexec) n += ge != nullptr;
+	return n;
 }
 
 // Diagnostic only (not part of include/nbldpc.h): in-kernel cycle stamps of the check-node kernel.
@@ -374,12 +400,107 @@ static nbl_status launch_cn(nbl_decoder *d, const NblRun &r, hipStream_t st)
 	return NBL_OK;
 }
 
-// The iteration loop of Decoding_BP / _EMS / _TEMS (NBLDPC.cpp:673 / 805 / 973), one launch triple per iteration.
+// The iteration loop of Decoding_BP / _EMS / _TEMS (NBLDPC.cpp:673 / 805 / 973): per iteration one fused launch + syndrome
+// (specialised (2,4)-regular shapes) or the launch triple VN, syndrome, CN.  The launches of a window of iterations are captured
+// into a hipGraph once and replayed (a decode is 100+ back-to-back launches: at small batches the gaps between them are most
+// of the time).
+struct IterCtx {
+	nbl_decoder *d;
+	NblRun r;
+	bool damp, fused;
+	double *bufA, *bufB;
+	// profiling: one event after every launch on the launch stream; phase time = sum of the gaps it closes
+	size_t nev = 0;
+	std::vector<int> tag; // 0 vn, 1 syn, 2 cn, 3 other
+};
+
+static hipError_t mark(IterCtx &c, int t, hipStream_t st)
+{
+	nbl_decoder *d = c.d;
+	if (!d->profiling) return hipSuccess;
+	if (c.nev == d->pev.size()) { hipEvent_t e; hipError_t rc = hipEventCreate(&e); if (rc != hipSuccess) return rc; d->pev.push_back(e); }
+	c.tag.push_back(t);
+	return hipEventRecord(d->pev[c.nev++], st);
+}
+
+// launches of iterations it_lo .. it_hi on `st`
+static nbl_status enqueue_window(IterCtx &c, int it_lo, int it_hi, hipStream_t st, bool count)
+{
+	nbl_decoder *d = c.d;
+	const nbl_params &p = d->prm;
+	for (int it = it_lo; it <= it_hi; it++) {
+		c.r.iter = it;
+		if (c.fused) {
+			// one launch = variable-node pass + check-node pass; c2v ping-pongs between the two buffers
+			NblWork wf = d->w;
+			wf.c2v_prev = (it & 1) ? c.bufA : c.bufB;
+			wf.c2v = (it & 1) ? c.bufB : c.bufA;
+			wf.store_v2c = d->record_state ? 1 : 0;
+			if (p.method == NBL_METHOD_EMS) HIP_TRY(d, nbl_launch_cn_ems256(d->g, wf, c.r, true, st));
+			else if (p.method == NBL_METHOD_TEMS && d->g.q == 64) HIP_TRY(d, nbl_launch_cn_tems64(d->g, wf, c.r, true, st));
+			else if (p.method == NBL_METHOD_TEMS) HIP_TRY(d, nbl_launch_cn_tems256(d->g, wf, c.r, true, st));
+			else HIP_TRY(d, nbl_launch_cn_bp256(d->g, wf, c.r, true, st));
+			HIP_TRY(d, mark(c, 2, st));
+			HIP_TRY(d, nbl_launch_syn(d->g, d->w, c.r, st));
+			HIP_TRY(d, mark(c, 1, st));
+			if (count) { d->launches[2]++; d->launches[1]++; }
+			continue;
+		}
+		HIP_TRY(d, nbl_launch_vn(d->g, d->w, c.r, c.damp, st));
+		HIP_TRY(d, mark(c, 0, st));
+		HIP_TRY(d, nbl_launch_syn(d->g, d->w, c.r, st));
+		HIP_TRY(d, mark(c, 1, st));
+		if (count) { d->launches[0]++; d->launches[1]++; }
+		// (the reference leaves the loop after the syndrome check of the last iteration it runs; the check-node pass of a
+		// window's last iteration is only needed if another window follows -- it is cheap to keep the windows uniform)
+		nbl_status s = launch_cn(d, c.r, st);
+		if (s) return s;
+		HIP_TRY(d, mark(c, 2, st));
+		if (count) d->launches[2]++;
+	}
+	return NBL_OK;
+}
+
+// Run window number `widx` (iterations it_lo..it_hi): replay its graph, capturing it first if needed; plain launches when
+// graphs are off, while profiling (events between the launches) or if the capture fails.
+static nbl_status run_window(IterCtx &c, int widx, int it_lo, int it_hi, hipStream_t st)
+{
+	nbl_decoder *d = c.d;
+	const bool graph_ok = d->use_graph && !d->profiling && !d->w.stamps;
+	if (graph_ok) {
+		if ((int)d->gexec.size() <= widx) d->gexec.resize(widx + 1, nullptr);
+		if (!d->gexec[widx]) {
+			hipGraph_t graph = nullptr;
+			if (hipStreamBeginCapture(d->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+				const nbl_status s = enqueue_window(c, it_lo, it_hi, d->stream, false);
+				const hipError_t e = hipStreamEndCapture(d->stream, &graph);
+				if (s == NBL_OK && e == hipSuccess && graph) {
+					if (hipGraphInstantiate(&d->gexec[widx], graph, nullptr, nullptr, 0) != hipSuccess) d->gexec[widx] = nullptr;
+				}
+				if (graph) (void)hipGraphDestroy(graph);
+				(void)hipGetLastError();
+			}
+			if (!d->gexec[widx]) d->use_graph = false; // capture is not available here: plain launches from now on
+		}
+		if (d->gexec[widx]) {
+			HIP_TRY(d, hipGraphLaunch(d->gexec[widx], st));
+			const int n = it_hi - it_lo + 1;
+			d->launches[1] += n; d->launches[2] += n;
+			if (!c.fused) d->launches[0] += n;
+			return NBL_OK;
+		}
+	}
+	return enqueue_window(c, it_lo, it_hi, st, true);
+}
+
 static nbl_status run_iterations(nbl_decoder *d, const double *d_Lin, int B, hipStream_t st)
 {
 	const nbl_params &p = d->prm;
-	const bool damp = p.method != NBL_METHOD_EMS;
-	NblRun r{};
+	IterCtx c;
+	c.d = d;
+	c.damp = p.method != NBL_METHOD_EMS;
+	NblRun &r = c.r;
+	r = NblRun{};
 	r.B = B;
 	r.fixed_iters = p.fixed_iters;
 	if (p.method == NBL_METHOD_EMS) { r.nm = p.ems_nm; r.nc = p.ems_nc; r.factor = p.ems_factor; r.offset = p.ems_offset; }
@@ -387,71 +508,41 @@ static nbl_status run_iterations(nbl_decoder *d, const double *d_Lin, int B, hip
 	r.damp_old = (p.method == NBL_METHOD_BP) ? 0.5 : 0.25;  // NBLDPC.cpp:739 / :1046
 	r.damp_new = (p.method == NBL_METHOD_BP) ? 0.5 : 0.75;
 	d->launches[0] = d->launches[1] = d->launches[2] = 0;
-	// profiling: one event after every launch on the launch stream; phase time = sum of the gaps it closes
-	size_t nev = 0;
-	std::vector<int> tag; // 0 vn, 1 syn, 2 cn, 3 other
-	auto mark = [&](int t) -> hipError_t {
-		if (!d->profiling) return hipSuccess;
-		if (nev == d->pev.size()) { hipEvent_t e; hipError_t rc = hipEventCreate(&e); if (rc != hipSuccess) return rc; d->pev.push_back(e); }
-		tag.push_back(t);
-		return hipEventRecord(d->pev[nev++], st);
-	};
-	HIP_TRY(d, mark(3));
-	HIP_TRY(d, nbl_launch_init(d_Lin, d->g, d->w, B, damp ? 1 : 0, st));
-	HIP_TRY(d, mark(3));
-	const bool fused = fused_shape(d) && d->force_generic == 0 && d->c2v_alt;
-	double *const bufA = d->w.c2v, *const bufB = d->c2v_alt;
-	d->last_c2v = bufA;
-	d->last_fused = fused;
-	for (int it = 1; it <= p.max_iter; it++) {
-		r.iter = it;
-		if (fused) {
-			// one launch = variable-node pass + check-node pass; c2v ping-pongs between the two buffers
-			NblWork wf = d->w;
-			wf.c2v_prev = (it & 1) ? bufA : bufB;
-			wf.c2v = (it & 1) ? bufB : bufA;
-			wf.store_v2c = d->record_state ? 1 : 0;
-			if (p.method == NBL_METHOD_EMS) HIP_TRY(d, nbl_launch_cn_ems256(d->g, wf, r, true, st));
-			else if (p.method == NBL_METHOD_TEMS && d->g.q == 64) HIP_TRY(d, nbl_launch_cn_tems64(d->g, wf, r, true, st));
-			else if (p.method == NBL_METHOD_TEMS) HIP_TRY(d, nbl_launch_cn_tems256(d->g, wf, r, true, st));
-			else HIP_TRY(d, nbl_launch_cn_bp256(d->g, wf, r, true, st));
-			HIP_TRY(d, mark(2));
-			d->launches[2]++;
-			d->last_c2v = wf.c2v;
-			HIP_TRY(d, nbl_launch_syn(d->g, d->w, r, st));
-			HIP_TRY(d, mark(1));
-			d->launches[1]++;
-			if (!p.fixed_iters && p.poll_every > 0 && (it % p.poll_every) == 0) {
-				int n_done = 0;
-				HIP_TRY(d, hipMemcpyAsync(&n_done, d->w.n_done, sizeof(int), hipMemcpyDeviceToHost, st));
-				HIP_TRY(d, hipStreamSynchronize(st));
-				if (n_done >= B) break;
-			}
-			continue;
-		}
-		HIP_TRY(d, nbl_launch_vn(d->g, d->w, r, damp, st));
-		HIP_TRY(d, mark(0));
-		HIP_TRY(d, nbl_launch_syn(d->g, d->w, r, st));
-		HIP_TRY(d, mark(1));
-		d->launches[0]++; d->launches[1]++;
-		if (!p.fixed_iters && p.poll_every > 0 && (it % p.poll_every) == 0) {
+	c.fused = fused_shape(d) && d->force_generic == 0 && d->c2v_alt;
+	c.bufA = d->w.c2v;
+	c.bufB = d->c2v_alt;
+	// the captured graphs hold buffer addresses and the batch size: any change drops them
+	const nbl_decoder::GraphKey key = {d_Lin, d->w.Lch, d->w.v2c, d->w.c2v, d->c2v_alt, d->w.post, B, d->record_state ? 1 : 0, d->force_generic, c.fused ? 1 : 0};
+	if (memcmp(&key, &d->gkey, sizeof key) != 0) { drop_graphs(d); d->gkey = key; }
+	HIP_TRY(d, mark(c, 3, st));
+	HIP_TRY(d, nbl_launch_init(d_Lin, d->g, d->w, B, c.damp ? 1 : 0, st));
+	HIP_TRY(d, mark(c, 3, st));
+	d->last_c2v = c.bufA;
+	d->last_fused = c.fused;
+	// windows: fixed iterations or no polling -> one window; early exit -> `poll_every` iterations, then ask the device
+	const bool polling = !p.fixed_iters && p.poll_every > 0;
+	const int wlen = polling ? p.poll_every : (p.max_iter > 0 ? p.max_iter : 1);
+	int last_it = 0;
+	for (int it_lo = 1, widx = 0; it_lo <= p.max_iter; it_lo += wlen, widx++) {
+		const int it_hi = (it_lo + wlen - 1 < p.max_iter) ? it_lo + wlen - 1 : p.max_iter;
+		nbl_status s = run_window(c, widx, it_lo, it_hi, st);
+		if (s) return s;
+		last_it = it_hi;
+		if (polling) {
 			int n_done = 0;
 			HIP_TRY(d, hipMemcpyAsync(&n_done, d->w.n_done, sizeof(int), hipMemcpyDeviceToHost, st));
 			HIP_TRY(d, hipStreamSynchronize(st));
 			if (n_done >= B) break;
 		}
-		nbl_status s = launch_cn(d, r, st);
-		if (s) return s;
-		HIP_TRY(d, mark(2));
-		d->launches[2]++;
 	}
-	if (d->profiling) {
-		HIP_TRY(d, hipEventSynchronize(d->pev[nev - 1]));
+	if (c.fused && last_it > 0) d->last_c2v = (last_it & 1) ? c.bufB : c.bufA;
+	if (d->profiling && c.nev > 0) {
+		HIP_TRY(d, hipEventSynchronize(d->pev[c.nev - 1]));
 		d->ms[0] = d->ms[1] = d->ms[2] = d->ms[3] = 0;
-		for (size_t i = 1; i < nev; i++) {
+		for (size_t i = 1; i < c.nev; i++) {
 			float ms = 0;
 			HIP_TRY(d, hipEventElapsedTime(&ms, d->pev[i - 1], d->pev[i]));
-			if (tag[i] < 3) d->ms[tag[i]] += ms;
+			if (c.tag[i] < 3) d->ms[c.tag[i]] += ms;
 			d->ms[3] += ms;
 		}
 	}
@@ -609,7 +700,6 @@ static nbl_status ensure_noise(nbl_decoder *d, int B)
 	HIP_TRY(d, hipMalloc((void **)&d->d_farg, cap * 8));
 	HIP_TRY(d, hipMalloc((void **)&d->d_fval, cap * 8));
 	if (!d->d_fcount) HIP_TRY(d, hipMalloc((void **)&d->d_fcount, 16));
-	HIP_TRY(d, hipHostMalloc((void **)&d->h_fidx, cap * 4, hipHostMallocDefault));
 	HIP_TRY(d, hipHostMalloc((void **)&d->h_farg, cap * 8, hipHostMallocDefault));
 	HIP_TRY(d, hipHostMalloc((void **)&d->h_fval, cap * 8, hipHostMallocDefault));
 	d->noise_cap = B;
@@ -643,16 +733,20 @@ static nbl_status run_channel(nbl_decoder *d, const uint8_t *tx_index, const uin
 	if (nflag > d->flag_cap) { d->err = "nbl_decode_batch_noise: more uncertain values than the list holds (30 % of all)"; return NBL_ERR_NOMEM; }
 	d->last_flag_frac = (double)nflag / ((double)B * L * 4);
 	if (nflag) {
-		HIP_TRY(d, hipMemcpyAsync(d->h_fidx, d->d_fidx, (size_t)nflag * 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(d, hipMemcpyAsync(d->h_farg, d->d_farg, (size_t)nflag * 8, hipMemcpyDeviceToHost, st));
 		HIP_TRY(d, hipStreamSynchronize(st));
-		// the host's own libm decides the uncertain values: log(1 - u1) (even index) or cos(2 pi u2) (odd index), Rand.cpp:35
+		// the host's own libm decides the uncertain values: log(1 - u1) or cos(2 pi u2), Rand.cpp:35
 		int T = (int)std::thread::hardware_concurrency();
 		if (const char *e = getenv("NBL_HOST_THREADS")) T = atoi(e);
 		if (T > 16) T = 16;
 		if (T < 1 || nflag < 4096) T = 1;
 		auto work = [&](unsigned lo, unsigned hi) {
-			for (unsigned k = lo; k < hi; k++) d->h_fval[k] = (d->h_fidx[k] & 1u) ? std::cos(d->h_farg[k]) : std::log(d->h_farg[k]);
+			// arguments of the logarithm are 1 - u1 in (0, 1]; arguments of the cosine are 2 pi u2 in [0, 2 pi): the list marks a
+			// cosine argument by its sign bit (the kernel stores -x, and -0.0 for x = 0), so only the arguments travel
+			for (unsigned k = lo; k < hi; k++) {
+				const double a = d->h_farg[k];
+				d->h_fval[k] = std::signbit(a) ? std::cos(-a) : std::log(a);
+			}
 		};
 		if (T == 1) work(0, nflag);
 		else {

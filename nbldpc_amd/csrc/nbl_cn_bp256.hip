@@ -73,7 +73,7 @@ struct Lds {
 };
 
 // out[z] = LSE_x(A[x] + B[z^x]) - LSE_x(A[x] + B[x]) for the lane's symbols z = 4 lane + i (log domain, out[0] = 0)
-__device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&out)[4], const Lds &s, int lane)
+__device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&out)[4], const Lds &s, int lane, unsigned long long *stamps)
 {
 	// Both operands are scaled by 2^500 for the plain-double path: an entry then survives down to e^-1054 of its vector's maximum
 	// and a product down to e^-1400 of the largest product.  Every output has a term >= e^-min(range) (the maximum of one vector
@@ -81,6 +81,10 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 	// with min(range) < 1000 nats nothing that matters underflows, and 256 products of at most 2^1000 cannot overflow.
 	constexpr int SH = 500;
 	const bool narrow = fmin(A.rng, B.rng) < 1000.0; // wave-uniform
+#ifdef NBL_EMS_STAMPS
+	// diagnostic build only (tools/bp_split.py): how many convolutions take the plain-double path / the mantissa-exponent path
+	if (stamps && lane == 0) atomicAdd(&stamps[narrow ? 0 : 1], 1ull);
+#endif
 	double lse[4];
 	if (narrow) {
 		s.Am01[lane] = make_double2(ldexp(A.m[0], A.e[0] + SH), ldexp(A.m[1], A.e[1] + SH));
@@ -269,21 +273,21 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 
 	double o[4];
 	// forward: F2 = p0 [+] p1, F3 = F2 [+] p2 = output 3 (A2 == 0 case, :761-764); output 2 = F2 [+] p3
-	lse_conv(p[0], p[1], o, s, lane);
+	lse_conv(p[0], p[1], o, s, lane, w.stamps);
 	{
 		const XVec F2 = to_xvec(o, lane);
-		lse_conv(F2, p[2], o, s, lane);
+		lse_conv(F2, p[2], o, s, lane, w.stamps);
 		emit(o, 3);
-		lse_conv(F2, p[3], o, s, lane);
+		lse_conv(F2, p[3], o, s, lane, w.stamps);
 		emit(o, 2);
 	}
 	// backward: R1 = p3 [+] p2, R0 = R1 [+] p1 = output 0 (A1 == 0 case, :757-760); output 1 = p0 [+] R1
-	lse_conv(p[3], p[2], o, s, lane);
+	lse_conv(p[3], p[2], o, s, lane, w.stamps);
 	{
 		const XVec R1 = to_xvec(o, lane);
-		lse_conv(R1, p[1], o, s, lane);
+		lse_conv(R1, p[1], o, s, lane, w.stamps);
 		emit(o, 0);
-		lse_conv(p[0], R1, o, s, lane);
+		lse_conv(p[0], R1, o, s, lane, w.stamps);
 		emit(o, 1);
 	}
 }

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void noise_gen_kernel(const uint32_t *__restri
 	}
 	if (!dd_certain(cs, NBL_BAND_COS)) {
 		const unsigned k = atomicAdd(flag_count, 1u);
-		if (k < cap) { flag_idx[k] = (uint32_t)(tid * 2 + 1); flag_arg[k] = x; }
+		if (k < cap) { flag_idx[k] = (uint32_t)(tid * 2 + 1); flag_arg[k] = -x; } // sign bit = "cosine" (x >= 0; -0.0 for x = 0)
 	}
 }
 

@@ -643,6 +643,35 @@ def test_generic_ems_beyond_64k_lds(oracle):
         dec.close()
 
 
+@pytest.mark.parametrize("name,fixed,poll", [("cfg2_ems_u128", 1, 0), ("cfg2_ems_u128", 0, 3), ("cfg4_tems_bds", 0, 2), ("cfg1_bp_gf16", 0, 2)])
+def test_hipgraph_replay_of_the_iteration_loop(monkeypatch, name, fixed, poll):
+    """NBL_GRAPH=1: the launches of every window of iterations are captured into a hipGraph at the first decode and replayed
+    afterwards (fixed iterations: one window; early exit: one per poll interval).  Same outputs as plain launches, call after call."""
+    g, meta = load_golden(name)
+    p, kw = meta["profile"], decoder_kwargs(meta["profile"])
+    code = nb.Code(meta["code"])
+    it = int(g["iters"][-1])
+    L = g["L_ch"]
+    monkeypatch.setenv("NBL_GRAPH", "0")
+    plain = nb.Decoder(code, p["method"], it, fixed_iters=fixed, poll_every=poll, **kw)
+    ref = plain.decode(L)
+    plain.close()
+    monkeypatch.setenv("NBL_GRAPH", "1")
+    dec = nb.Decoder(code, p["method"], it, fixed_iters=fixed, poll_every=poll, **kw)
+    dec.lib.nbl_debug_graph_windows.argtypes = [C.c_void_p]
+    for rep in range(3):
+        got = dec.decode(L)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), (name, rep)
+        assert dec.lib.nbl_debug_graph_windows(dec.h) >= 1, "the graph path did not engage"
+    # a different batch size drops the captured graphs and captures again
+    got = dec.decode(L[:2])
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b[:2])
+    assert dec.lib.nbl_debug_graph_windows(dec.h) >= 1
+    dec.close()
+
+
 def test_device_pointer_entry_point():
     import torch
     g, meta = load_golden("cfg2_ems_u128")

@@ -1,7 +1,8 @@
 #!/bin/bash
 # rocprofv3 passes for one workload, each in its own run (gpurun refuses --pmc together with trace domains):
 #   tools/profile.sh <tag> <program...>      e.g.  tools/profile.sh r02 python3 bench.py --steps 2 --warmup 1 --cpu-sample 0
-# Output directories gpurun_out/prof_<tag>_{stats,sq1,sq2,fetch,write}; condense with tools/summarize_profiles.py.
+# The rocpd databases (tens of MB each) stay on the GPU box: the last step condenses them into profiles/<tag>_summary.json and
+# profiles/<tag>_kernel_stats.csv, copied to gpurun_out/ so that they travel back (gpurun merges at most 64 MiB).
 # The program itself follows `--` (no env/bash hop: the profiler's preloaded library has already initialised the GPU).
 set -e
 tag=$1; shift
@@ -17,3 +18,7 @@ rocprofv3 --pmc FETCH_SIZE -d $out/prof_${tag}_fetch -- "$@" > $out/prof_${tag}_
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE -d $out/prof_${tag}_write -- "$@" > $out/prof_${tag}_write.log 2>&1
 echo "write done"
+python3 tools/summarize_profiles.py $tag "$*" > $out/prof_${tag}_summary.log 2>&1
+cp profiles/${tag}_summary.json profiles/${tag}_kernel_stats.csv $out/
+rm -rf $out/prof_${tag}_stats $out/prof_${tag}_sq1 $out/prof_${tag}_sq2 $out/prof_${tag}_fetch $out/prof_${tag}_write
+echo "summary done"
