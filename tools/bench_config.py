@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the other BASELINE.json configurations (parity-test cases, not the headline bench line).
 
-usage: python tools/bench_config.py cfg2|cfg3|cfg3nc2|cfg4|cfg5|tems256|ems64|bp64|ems16|tems16|bp16 [batch] [steps]
+usage: python tools/bench_config.py cfg2|cfg3|cfg3nc2|cfg4|cfg5|tems256|ems64|bp64|ems16|tems16|bp16 [batch] [steps] [ebn0]
 Prints one JSON line: codewords/s at fixed iterations with HBM-resident inputs, plus the algorithmic-bytes roofline fraction
 (8(q-1)[N + I(N + 4E + D E)] + 4N + 4 bytes per codeword, D = 1 for BP / T-EMS).
 """
@@ -59,6 +59,8 @@ def main():
     c = CFG[name]
     B = int(sys.argv[2]) if len(sys.argv) > 2 else c["batch"]
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    if len(sys.argv) > 4:
+        c = dict(c, ebn0=float(sys.argv[4]))
     dev = torch.device("cuda", 0)
     code = nb.Code(c["code"])
     L = synth(code, B, c["ebn0"], c["mod"], dev).contiguous()
@@ -83,7 +85,7 @@ def main():
     cws = B * steps / dt
     print(json.dumps({"config": name, "code": c["code"], "method": c["method"], "iters": I, "batch": B, "codewords_per_s": cws,
                       "ms_per_batch": dt / steps * 1e3, "algorithmic_GBps": cws * bytes_cw / 1e9, "hbm_frac": cws * bytes_cw / 8e12,
-                      "converged_frac": float(conv.float().mean().item()),
+                      "converged_frac": float(conv.float().mean().item()), "ebn0": c["ebn0"],
                       "phase_ms": {"vn": phase_ms[0], "syndrome": phase_ms[1], "cn": phase_ms[2]}, "launches": launches}))
 
 
