@@ -618,16 +618,27 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 				acc[p][3] = dmax(acc[p][3], (SW ? rb[p].x : rb[p].y) + en.v);
 			}
 		};
+		// the list lives in the registers of lanes 0..NM-1 (one entry each); an entry reaches the whole wave through v_readlane
+		// (SGPR operands of the adds) -- the LDS port is the busier resource of this kernel, a broadcast read per entry costs more
+		const double myv = lstv[jc * NM + (lane & (NM - 1))];
+		const int mytt = lstt[jc * NM + (lane & (NM - 1))].y;
+		auto entry = [&](int k) {
+			ListEnt e;
+			e.v = read_lane_f64(myv, k);
+			e.tt = __builtin_amdgcn_readlane(mytt, k);
+			e.t8 = 0;
+			return e;
+		};
 		auto run = [&](int k0, int k1, auto swapped) {
 			int k = k0;
 			for (; k + UN <= k1; k += UN) {
 				ListEnt en[UN];
 #pragma unroll
-				for (int u = 0; u < UN; u++) en[u] = list_at(jc, k + u); // same address in every lane: LDS broadcast
+				for (int u = 0; u < UN; u++) en[u] = entry(k + u);
 #pragma unroll
 				for (int u = 0; u < UN; u++) body(en[u], swapped);
 			}
-			for (; k < k1; k++) body(list_at(jc, k), swapped);
+			for (; k < k1; k++) body(entry(k), swapped);
 		};
 		run(0, n0[jc], std::false_type{});
 		run(n0[jc], NM, std::true_type{});
