@@ -123,6 +123,13 @@ nbl_status nbl_decode_batch_samples(nbl_decoder *dec, const double *rx, double s
  * its copy of each lane's generator on with nbl_rand_advance(state, 4 L). */
 nbl_status nbl_decode_batch_noise(nbl_decoder *dec, const uint8_t *tx_index, const uint32_t *lane_state, double sigma, int32_t B,
                                   int32_t *out_sym, uint8_t *converged, int32_t *iters);
+/* The same in two phases, for callers that overlap the channel of batch k+1 with the decode of batch k (two host threads):
+ * nbl_channel_batch forms the samples of a batch into the decoder's resident buffer `slot` (0 or 1) on a second stream and returns
+ * when they are complete; nbl_decode_batch_resident demodulates and decodes what a slot holds.  A channel call and a decode call
+ * on DIFFERENT slots may run concurrently; otherwise the handle is single-threaded like every other call. */
+nbl_status nbl_channel_batch(nbl_decoder *dec, int32_t slot, const uint8_t *tx_index, const uint32_t *lane_state, double sigma, int32_t B);
+nbl_status nbl_decode_batch_resident(nbl_decoder *dec, int32_t slot, double sigma, int32_t B, int32_t *out_sym, uint8_t *converged,
+                                     int32_t *iters);
 /* state <- state after `draws` calls of CRand::Rand_Uniform (Rand.cpp:17-28); pure host arithmetic */
 void nbl_rand_advance(uint32_t state[3], uint64_t draws);
 

@@ -17,7 +17,7 @@ METHOD_BP, METHOD_EMS, METHOD_TEMS = 1, 2, 4
 
 # every symbol include/nbldpc.h declares
 EXPORTS = ("nbl_abi_version", "nbl_create", "nbl_destroy", "nbl_decode_batch", "nbl_decode_batch_device",
-           "nbl_set_demodulator", "nbl_decode_batch_samples", "nbl_decode_batch_noise", "nbl_rand_advance",
+           "nbl_set_demodulator", "nbl_decode_batch_samples", "nbl_decode_batch_noise", "nbl_rand_advance", "nbl_channel_batch", "nbl_decode_batch_resident",
            "nbl_read_state", "nbl_set_record_state", "nbl_set_profiling", "nbl_last_timing", "nbl_last_error",
            "nbl_workspace_bytes")
 
@@ -178,6 +178,20 @@ class Decoder:
         iters = np.zeros(B, dtype=np.int32)
         self.lib.nbl_decode_batch_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         self._chk(self.lib.nbl_decode_batch_noise(self.h, tx_index.ctypes.data, lane_state.ctypes.data, sigma, B, out.ctypes.data, conv.ctypes.data, iters.ctypes.data))
+        return out, conv, iters
+
+    def channel_batch(self, slot, tx_index, lane_state, sigma):
+        tx_index = np.ascontiguousarray(tx_index, dtype=np.uint8)
+        lane_state = np.ascontiguousarray(lane_state, dtype=np.uint32)
+        self.lib.nbl_channel_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_int32]
+        self._chk(self.lib.nbl_channel_batch(self.h, slot, tx_index.ctypes.data, lane_state.ctypes.data, sigma, tx_index.shape[0]))
+
+    def decode_resident(self, slot, sigma, B):
+        out = np.zeros((B, self.code.N), dtype=np.int32)
+        conv = np.zeros(B, dtype=np.uint8)
+        iters = np.zeros(B, dtype=np.int32)
+        self.lib.nbl_decode_batch_resident.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.nbl_decode_batch_resident(self.h, slot, sigma, B, out.ctypes.data, conv.ctypes.data, iters.ctypes.data))
         return out, conv, iters
 
     def channel(self, tx_index, lane_state, sigma):

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <cmath>
 #include <string>
 #include <thread>
@@ -53,6 +54,11 @@ struct nbl_decoder {
 	double *h_farg = nullptr, *h_fval = nullptr;
 	size_t noise_cap = 0, flag_cap = 0;
 	double last_flag_frac = 0.0;
+	hipStream_t stream2 = nullptr; // the channel of batch k+1 runs here while batch k is decoded on `stream`
+	double *d_rxs[2] = {nullptr, nullptr}; // resident received samples of nbl_channel_batch, one per slot
+	size_t d_rxs_cap[2] = {0, 0};
+	int rxs_B[2] = {0, 0};
+	std::string err2;              // error text of the channel thread (nbl_last_error reports err first)
 	// hipGraph replay of the iteration loop: one executable graph per window of iterations (fixed iterations: the whole loop;
 	// early exit: the `poll_every` iterations between two polls), captured on the decoder's own stream the first time a window is
 	// run with a given set of buffers, replayed on the caller's stream afterwards.  NBL_GRAPH=0 switches it off.
@@ -63,6 +69,7 @@ struct nbl_decoder {
 	int force_generic = 0;      // debug: 1 = always the generic kernels, 2 = specialised kernels but no VN/CN fusion
 	bool profiling = false;
 	hipEvent_t ev[2] = {nullptr, nullptr};
+	int *h_ndone = nullptr;      // pinned [2]: converged-codeword counts read back after each window of iterations
 	std::vector<hipEvent_t> pev; // per-launch events (profiling only)
 	double ms[4] = {0, 0, 0, 0};
 	long long launches[3] = {0, 0, 0};
@@ -308,12 +315,16 @@ extern "C" void nbl_destroy(nbl_decoder *d)
 	if (d->d_src) (void)hipFree(d->d_src);
 	if (d->d_cons) (void)hipFree(d->d_cons);
 	if (d->d_rx) (void)hipFree(d->d_rx);
+	for (double *p : d->d_rxs)
+		if (p) (void)hipFree(p);
+	if (d->stream2) { (void)hipStreamSynchronize(d->stream2); (void)hipStreamDestroy(d->stream2); }
 	for (void *p : {(void *)d->d_jump, (void *)d->d_state, (void *)d->d_txi, (void *)d->d_fn, (void *)d->d_fidx, (void *)d->d_farg, (void *)d->d_fval, (void *)d->d_fcount})
 		if (p) (void)hipFree(p);
 	for (void *p : {(void *)d->h_fidx, (void *)d->h_farg, (void *)d->h_fval})
 		if (p) (void)hipHostFree(p);
 	for (auto &e : d->ev)
 		if (e) (void)hipEventDestroy(e);
+	if (d->h_ndone) (void)hipHostFree(d->h_ndone);
 	for (auto &e : d->pev) (void)hipEventDestroy(e);
 	if (d->stream) (void)hipStreamDestroy(d->stream);
 	delete d;
@@ -523,18 +534,28 @@ static nbl_status run_iterations(nbl_decoder *d, const double *d_Lin, int B, hip
 	const bool polling = !p.fixed_iters && p.poll_every > 0;
 	const int wlen = polling ? p.poll_every : (p.max_iter > 0 ? p.max_iter : 1);
 	int last_it = 0;
+	if (polling && !d->h_ndone) HIP_TRY(d, hipHostMalloc((void **)&d->h_ndone, 2 * sizeof(int), hipHostMallocDefault));
+	// Early exit without idling the GPU: window w+1 is queued BEFORE the host looks at the count of converged codewords that
+	// window w left behind (read back through pinned memory behind an event).  If everything had converged, the extra window
+	// finds every codeword frozen and its kernels return at once; outputs, flags and iteration counts are unaffected.
+	int pending = -1; // parity of the read-back that has not been looked at yet
 	for (int it_lo = 1, widx = 0; it_lo <= p.max_iter; it_lo += wlen, widx++) {
 		const int it_hi = (it_lo + wlen - 1 < p.max_iter) ? it_lo + wlen - 1 : p.max_iter;
 		nbl_status s = run_window(c, widx, it_lo, it_hi, st);
 		if (s) return s;
 		last_it = it_hi;
 		if (polling) {
-			int n_done = 0;
-			HIP_TRY(d, hipMemcpyAsync(&n_done, d->w.n_done, sizeof(int), hipMemcpyDeviceToHost, st));
-			HIP_TRY(d, hipStreamSynchronize(st));
-			if (n_done >= B) break;
+			const int par = widx & 1;
+			HIP_TRY(d, hipMemcpyAsync(&d->h_ndone[par], d->w.n_done, sizeof(int), hipMemcpyDeviceToHost, st));
+			HIP_TRY(d, hipEventRecord(d->ev[par], st));
+			if (pending >= 0) {
+				HIP_TRY(d, hipEventSynchronize(d->ev[pending]));
+				if (d->h_ndone[pending] >= B) break;
+			}
+			pending = par;
 		}
 	}
+	if (polling) HIP_TRY(d, hipStreamSynchronize(st));
 	if (c.fused && last_it > 0) d->last_c2v = (last_it & 1) ? c.bufB : c.bufA;
 	if (d->profiling && c.nev > 0) {
 		HIP_TRY(d, hipEventSynchronize(d->pev[c.nev - 1]));
@@ -707,8 +728,10 @@ static nbl_status ensure_noise(nbl_decoder *d, int B)
 	return NBL_OK;
 }
 
-// Forms RX = TX + noise in d->d_rx for B lanes (the three kernels of nbl_noise.hip with the host's libm in between).
-static nbl_status run_channel(nbl_decoder *d, const uint8_t *tx_index, const uint32_t *lane_state, double sigma, int B)
+// Forms RX = TX + noise for B lanes in *rx_buf (grown on demand) on stream `st`: the three kernels of nbl_noise.hip with the host's
+// libm in between.  Returns with the samples complete in HBM.
+static nbl_status run_channel(nbl_decoder *d, const uint8_t *tx_index, const uint32_t *lane_state, double sigma, int B, hipStream_t st,
+                              double **rx_buf, size_t *rx_cap)
 {
 	if (!d->dm_order) { d->err = "nbl_set_demodulator has not been called"; return NBL_ERR_ARG; }
 	if (d->h_cons.empty() || !d->d_cons) { d->err = "the channel needs the constellation points (nbl_demod_desc.constellation), also for BPSK"; return NBL_ERR_ARG; }
@@ -716,13 +739,16 @@ static nbl_status run_channel(nbl_decoder *d, const uint8_t *tx_index, const uin
 	if (s) return s;
 	const size_t L = d->dm_L;
 	const size_t bytes = (size_t)B * L * 16;
-	if (bytes > d->d_rx_cap) {
-		if (d->d_rx) (void)hipFree(d->d_rx);
-		d->d_rx = nullptr;
-		HIP_TRY(d, hipMalloc((void **)&d->d_rx, bytes));
-		d->d_rx_cap = bytes;
+	if (bytes > *rx_cap) {
+		if (*rx_buf) (void)hipFree(*rx_buf);
+		*rx_buf = nullptr;
+		HIP_TRY(d, hipMalloc((void **)rx_buf, bytes));
+		*rx_cap = bytes;
 	}
-	hipStream_t st = d->stream;
+	const bool timing = getenv("NBL_CHANNEL_TIMING") != nullptr;
+	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t0 = now();
+	double t1 = t0, t2 = t0, t3 = t0;
 	HIP_TRY(d, hipMemcpyAsync(d->d_state, lane_state, (size_t)B * 12, hipMemcpyHostToDevice, st));
 	HIP_TRY(d, hipMemcpyAsync(d->d_txi, tx_index, (size_t)B * L, hipMemcpyHostToDevice, st));
 	HIP_TRY(d, hipMemsetAsync(d->d_fcount, 0, 4, st));
@@ -732,9 +758,11 @@ static nbl_status run_channel(nbl_decoder *d, const uint8_t *tx_index, const uin
 	HIP_TRY(d, hipStreamSynchronize(st));
 	if (nflag > d->flag_cap) { d->err = "nbl_decode_batch_noise: more uncertain values than the list holds (30 % of all)"; return NBL_ERR_NOMEM; }
 	d->last_flag_frac = (double)nflag / ((double)B * L * 4);
+	t1 = now();
 	if (nflag) {
 		HIP_TRY(d, hipMemcpyAsync(d->h_farg, d->d_farg, (size_t)nflag * 8, hipMemcpyDeviceToHost, st));
 		HIP_TRY(d, hipStreamSynchronize(st));
+		t2 = now();
 		// the host's own libm decides the uncertain values: log(1 - u1) or cos(2 pi u2), Rand.cpp:35
 		int T = (int)std::thread::hardware_concurrency();
 		if (const char *e = getenv("NBL_HOST_THREADS")) T = atoi(e);
@@ -754,10 +782,15 @@ static nbl_status run_channel(nbl_decoder *d, const uint8_t *tx_index, const uin
 			for (int t = 0; t < T; t++) th.emplace_back(work, (unsigned)((uint64_t)nflag * t / T), (unsigned)((uint64_t)nflag * (t + 1) / T));
 			for (auto &x : th) x.join();
 		}
+		t3 = now();
 		HIP_TRY(d, hipMemcpyAsync(d->d_fval, d->h_fval, (size_t)nflag * 8, hipMemcpyHostToDevice, st));
 		HIP_TRY(d, nbl_launch_noise_patch(d->d_fn, d->d_fidx, d->d_fval, nflag, st));
 	}
-	HIP_TRY(d, nbl_launch_noise_finish(d->d_fn, d->d_txi, d->d_cons, sigma, (int)L, B, d->d_rx, st));
+	HIP_TRY(d, nbl_launch_noise_finish(d->d_fn, d->d_txi, d->d_cons, sigma, (int)L, B, *rx_buf, st));
+	HIP_TRY(d, hipStreamSynchronize(st));
+	if (timing)
+		fprintf(stderr, "[channel] B=%d: generate %.2f ms, list to host %.2f ms, host libm (%u values) %.2f ms, patch + finish %.2f ms\n", B,
+		        (t1 - t0) * 1e3, (t2 - t1) * 1e3, nflag, (t3 - t2) * 1e3, (now() - t3) * 1e3);
 	return NBL_OK;
 }
 
@@ -769,8 +802,36 @@ extern "C" nbl_status nbl_decode_batch_noise(nbl_decoder *d, const uint8_t *tx_i
 	HIP_TRY(d, hipSetDevice(d->device));
 	nbl_status s = ensure_workspace(d, B);
 	if (s) return s;
-	if ((s = run_channel(d, tx_index, lane_state, sigma, B))) return s;
+	if ((s = run_channel(d, tx_index, lane_state, sigma, B, d->stream, &d->d_rx, &d->d_rx_cap))) return s;
 	HIP_TRY(d, nbl_launch_demod(d->d_rx, d->dm_L, sigma, d->dm_order, d->d_cons, d->d_src, d->g, d->w, B, d->stream));
+	if ((s = run_iterations(d, nullptr, B, d->stream))) return s;
+	HIP_TRY(d, hipMemcpyAsync(out_sym, d->w.out, (size_t)B * d->g.N * 4, hipMemcpyDeviceToHost, d->stream));
+	if (converged) HIP_TRY(d, hipMemcpyAsync(converged, d->w.done, (size_t)B, hipMemcpyDeviceToHost, d->stream));
+	if (iters) HIP_TRY(d, hipMemcpyAsync(iters, d->w.iters, (size_t)B * 4, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(d, hipStreamSynchronize(d->stream));
+	return NBL_OK;
+}
+
+// Two-phase form: the channel of batch k+1 (second stream, host libm) may run on another host thread while batch k is decoded.
+extern "C" nbl_status nbl_channel_batch(nbl_decoder *d, int32_t slot, const uint8_t *tx_index, const uint32_t *lane_state, double sigma, int32_t B)
+{
+	if (!d || !tx_index || !lane_state || B <= 0 || slot < 0 || slot > 1 || !(sigma > 0)) return NBL_ERR_ARG;
+	if (hipSetDevice(d->device) != hipSuccess) return NBL_ERR_HIP;
+	if (!d->stream2 && hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking) != hipSuccess) return NBL_ERR_HIP;
+	d->rxs_B[slot] = 0;
+	const nbl_status s = run_channel(d, tx_index, lane_state, sigma, B, d->stream2, &d->d_rxs[slot], &d->d_rxs_cap[slot]);
+	if (s == NBL_OK) d->rxs_B[slot] = B;
+	return s;
+}
+
+extern "C" nbl_status nbl_decode_batch_resident(nbl_decoder *d, int32_t slot, double sigma, int32_t B, int32_t *out_sym, uint8_t *converged, int32_t *iters)
+{
+	if (!d || !out_sym || B <= 0 || slot < 0 || slot > 1 || !(sigma > 0)) return NBL_ERR_ARG;
+	if (d->rxs_B[slot] != B) { d->err = "nbl_decode_batch_resident: slot does not hold the samples of a batch of this size (nbl_channel_batch first)"; return NBL_ERR_ARG; }
+	HIP_TRY(d, hipSetDevice(d->device));
+	nbl_status s = ensure_workspace(d, B);
+	if (s) return s;
+	HIP_TRY(d, nbl_launch_demod(d->d_rxs[slot], d->dm_L, sigma, d->dm_order, d->d_cons, d->d_src, d->g, d->w, B, d->stream));
 	if ((s = run_iterations(d, nullptr, B, d->stream))) return s;
 	HIP_TRY(d, hipMemcpyAsync(out_sym, d->w.out, (size_t)B * d->g.N * 4, hipMemcpyDeviceToHost, d->stream));
 	if (converged) HIP_TRY(d, hipMemcpyAsync(converged, d->w.done, (size_t)B, hipMemcpyDeviceToHost, d->stream));
@@ -786,7 +847,7 @@ extern "C" nbl_status nbl_debug_channel(nbl_decoder *d, const uint8_t *tx_index,
 {
 	if (!d || !tx_index || !lane_state || !rx_out || B <= 0) return NBL_ERR_ARG;
 	HIP_TRY(d, hipSetDevice(d->device));
-	nbl_status s = run_channel(d, tx_index, lane_state, sigma, B);
+	nbl_status s = run_channel(d, tx_index, lane_state, sigma, B, d->stream, &d->d_rx, &d->d_rx_cap);
 	if (s) return s;
 	HIP_TRY(d, hipMemcpyAsync(rx_out, d->d_rx, (size_t)B * d->dm_L * 16, hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(d, hipStreamSynchronize(d->stream));

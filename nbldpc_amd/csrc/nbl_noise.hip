@@ -14,6 +14,7 @@
 //   noise_finish_kernel  RX = TX + (0 + sigma * cs * sqrt(-2 lg)) in the reference's expression order
 #include <hip/hip_runtime.h>
 #include "nbl_ddmath.h"
+#include "nbl_device.h"
 #include "nbl_kernels.h"
 
 __global__ __launch_bounds__(256) void noise_gen_kernel(const uint32_t *__restrict__ state, const uint32_t *__restrict__ jump, int L,
@@ -45,13 +46,22 @@ __global__ __launch_bounds__(256) void noise_gen_kernel(const uint32_t *__restri
 	r.x = lg.hi;
 	r.y = cs.hi;
 	fn[tid] = r;
-	if (!dd_certain(lg, NBL_BAND_LOG)) {
-		const unsigned k = atomicAdd(flag_count, 1u);
-		if (k < cap) { flag_idx[k] = (uint32_t)(tid * 2); flag_arg[k] = v; }
-	}
-	if (!dd_certain(cs, NBL_BAND_COS)) {
-		const unsigned k = atomicAdd(flag_count, 1u);
-		if (k < cap) { flag_idx[k] = (uint32_t)(tid * 2 + 1); flag_arg[k] = -x; } // sign bit = "cosine" (x >= 0; -0.0 for x = 0)
+	// uncertain values go to the list: one atomic per wave (ballots + prefix counts), not one per value
+	const bool ul = !dd_certain(lg, NBL_BAND_LOG), uc = !dd_certain(cs, NBL_BAND_COS);
+	const uint64_t ml = __ballot(ul), mc = __ballot(uc);
+	const int nl = __builtin_popcountll(ml), ncs = __builtin_popcountll(mc);
+	if (nl + ncs) {
+		unsigned base = 0;
+		if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(ml | mc)) base = atomicAdd(flag_count, (unsigned)(nl + ncs));
+		base = (unsigned)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(ml | mc));
+		if (ul) {
+			const unsigned k = base + (unsigned)prefix_count(ml);
+			if (k < cap) { flag_idx[k] = (uint32_t)(tid * 2); flag_arg[k] = v; }
+		}
+		if (uc) {
+			const unsigned k = base + (unsigned)nl + (unsigned)prefix_count(mc);
+			if (k < cap) { flag_idx[k] = (uint32_t)(tid * 2 + 1); flag_arg[k] = -x; } // sign bit = "cosine" (x >= 0; -0.0 for x = 0)
+		}
 	}
 }
 

@@ -105,10 +105,35 @@ void CLink::FrontEnds(int slot)
 			lanes[i]->HoldTx(slot);
 		}
 	});
+	if (device_noise) channel_ok[slot] = Channel(slot);
+}
+
+// device-side AWGN channel of the frames the front-ends just produced (second stream of every decoder): in the pipelined
+// driver this runs while the previous cycle is being decoded
+bool CLink::Channel(int slot)
+{
+	const int P = sim.parallel, G = (int)devices.size(), L = lanes[0]->MOD_SYM_LEN;
+	const double sigma = lanes[0]->sigma_n;
+	std::vector<int> rc(G, 0);
+	auto shard = [&](int gidx) {
+		const int lo = (int)((long long)P * gidx / G), hi = (int)((long long)P * (gidx + 1) / G);
+		CNBLDPC &dec = gidx == 0 ? code : *extra[gidx - 1];
+		if (hi > lo) rc[gidx] = dec.ChannelBatch(slot, &txi_batch[slot][(size_t)L * lo], &state_batch[slot][(size_t)3 * lo], sigma, hi - lo);
+	};
+	if (G == 1) shard(0);
+	else {
+		std::vector<std::thread> th;
+		for (int gidx = 0; gidx < G; gidx++) th.emplace_back(shard, gidx);
+		for (auto &x : th) x.join();
+	}
+	for (int gidx = 0; gidx < G; gidx++)
+		if (rc[gidx] != 0) { error = (gidx == 0 ? code : *extra[gidx - 1]).LastError(); return false; }
+	return true;
 }
 
 bool CLink::Decode(int slot)
 {
+	if (device_noise && !channel_ok[slot]) return false;
 	const int P = sim.parallel;
 	const size_t per = (size_t)code.CodeLen * (code.GFq - 1);
 	const int G = (int)devices.size();
@@ -119,8 +144,7 @@ bool CLink::Decode(int slot)
 		const int lo = (int)((long long)P * gidx / G), hi = (int)((long long)P * (gidx + 1) / G);
 		CNBLDPC &dec = gidx == 0 ? code : *extra[gidx - 1];
 		if (hi > lo && device_noise)
-			rc[gidx] = dec.DecodingBatchNoise(&txi_batch[slot][(size_t)lanes[0]->MOD_SYM_LEN * lo], &state_batch[slot][(size_t)3 * lo], sigma, hi - lo,
-			                                  &out_batch[(size_t)code.CodeLen * lo], &conv[lo], &iters[lo]);
+			rc[gidx] = dec.DecodingBatchResident(slot, sigma, hi - lo, &out_batch[(size_t)code.CodeLen * lo], &conv[lo], &iters[lo]);
 		else if (hi > lo)
 			rc[gidx] = device_demod
 			    ? dec.DecodingBatchSamples(&rx_batch[slot][rxper * lo], sigma, hi - lo, &out_batch[(size_t)code.CodeLen * lo], &conv[lo], &iters[lo])

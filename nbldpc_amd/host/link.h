@@ -20,6 +20,8 @@ public:
 	                                   // NBL_DEVICE_NOISE=0 draws the noise on the host threads.  Needs device_demod.
 	std::vector<unsigned char> txi_batch[2]; // [parallel][MOD_SYM_LEN] constellation indices
 	std::vector<unsigned int> state_batch[2]; // [parallel][3] generator states in front of the frame
+	bool channel_ok[2] = {true, true};
+	bool Channel(int slot);            // device-side channel of the slot's frames (runs under the previous cycle's decode)
 	bool pipeline = true;              // NBL_PIPELINE=0: strictly serial cycles
 	int host_threads = 1;
 	std::vector<int> out_batch, iters;

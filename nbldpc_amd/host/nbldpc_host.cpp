@@ -157,6 +157,22 @@ int CNBLDPC::DecodingBatchNoise(const unsigned char *tx_index, const unsigned in
 	return 0;
 }
 
+int CNBLDPC::ChannelBatch(int slot, const unsigned char *tx_index, const unsigned int *lane_state, double sigma, int B)
+{
+	if (!dec) { error = "decoder not initialised"; return -1; }
+	nbl_status st = nbl_channel_batch(dec, slot, tx_index, lane_state, sigma, B);
+	if (st != NBL_OK) { error = nbl_last_error(dec); std::cerr << error << std::endl; return (int)st; }
+	return 0;
+}
+
+int CNBLDPC::DecodingBatchResident(int slot, double sigma, int B, int *out, uint8_t *converged, int *iters)
+{
+	if (!dec) { error = "decoder not initialised"; return -1; }
+	nbl_status st = nbl_decode_batch_resident(dec, slot, sigma, B, out, converged, iters);
+	if (st != NBL_OK) { error = nbl_last_error(dec); std::cerr << error << std::endl; return (int)st; }
+	return 0;
+}
+
 int CNBLDPC::Decoding(double **L_ch, int *DecodeOutput, int *, int *) // NBLDPC.cpp:607
 {
 	std::vector<double> flat((size_t)CodeLen * (GFq - 1));

@@ -42,6 +42,9 @@ public:
 	// device-side channel (replaces CComm::Channel_AWGN + CRand, Comm.cpp:328-337 / Rand.cpp:17-37): tx_index [B][L] constellation
 	// indices, lane_state [B][3] generator states in front of the frame
 	int DecodingBatchNoise(const unsigned char *tx_index, const unsigned int *lane_state, double sigma, int B, int *out, uint8_t *converged, int *iters);
+	// the same in two phases (slot 0 / 1): the channel of cycle k+1 may run while cycle k is decoded
+	int ChannelBatch(int slot, const unsigned char *tx_index, const unsigned int *lane_state, double sigma, int B);
+	int DecodingBatchResident(int slot, double sigma, int B, int *out, uint8_t *converged, int *iters);
 	const std::string &LastError() const { return error; }
 	nbl_decoder *Handle() const { return dec; }
 

@@ -61,3 +61,31 @@ def test_rand_advance_matches_the_lanes(tmp_path):
         for f in (1, 2):
             lib.nbl_rand_advance(st.ctypes.data, 4 * L)
             assert np.array_equal(st, state[f * 64 + lane])
+
+
+def test_two_phase_channel_overlaps_the_decode(tmp_path):
+    """nbl_channel_batch (slot s) + nbl_decode_batch_resident (slot s) = nbl_decode_batch_noise; and the channel of the next batch
+    may run on another host thread while the current one is decoded -- what the pipelined harness does."""
+    import threading
+    P, frames = 1024, 4
+    code, points, L, q = _setup(tmp_path, "divsalar.UNBLDPC.128.64.GF.256", "BPSK", 2, P, 99, ems_nm=16, ems_nc=3)
+    rx, txi, state, sigma = hostlib.channel(str(tmp_path), 2.0, frames, L, P)
+    dec = nb.Decoder(code, nb.METHOD_EMS, 10, ems_nm=16, ems_nc=3, poll_every=2)
+    dec.set_demodulator(2, L, np.arange(L), points)
+    ref = [dec.decode_noise(txi[f * P:(f + 1) * P], state[f * P:(f + 1) * P], sigma) for f in range(frames)]
+    # pipelined: channel of frame f+1 under the decode of frame f
+    dec.channel_batch(0, txi[:P], state[:P], sigma)
+    for f in range(frames):
+        slot = f & 1
+        th = None
+        if f + 1 < frames:
+            th = threading.Thread(target=dec.channel_batch, args=(slot ^ 1, txi[(f + 1) * P:(f + 2) * P], state[(f + 1) * P:(f + 2) * P], sigma))
+            th.start()
+        got = dec.decode_resident(slot, sigma, P)
+        if th:
+            th.join()
+        for a, b in zip(got, ref[f]):
+            assert np.array_equal(a, b), f
+    with pytest.raises(nb.NblError):
+        dec.decode_resident(0, sigma, P // 2)   # the slot holds a batch of another size
+    dec.close()
