@@ -290,6 +290,14 @@ def test_tems_gf64_every_shape_ties_and_erasures_vs_oracle(oracle, codename, ite
     run(Li, dict(tems_nr=nr, tems_nc=nc, tems_factor=1.0, tems_offset=0.0), [oracle.CANONICAL, oracle.LITERAL])
 
 
+def test_tems_gf256_nr3_nc2_integer_llr_regression(oracle):
+    """Named regression guard: GF(256), nr = 3, nc = 2, integer LLRs -- the shape on which the first layout of the
+    GF(256) T-EMS kernel's DP state produced wrong path codes at -O2/-O3 (nbl_cn_tems256.hip header; attributed to hipcc's late
+    GVN over promoted vector values, our own type punning of the phased LDS region not ruled out).  Every kernel variant must
+    equal the oracle's enumeration bit for bit; a compiler bump or a refactor that brings the fault back fails here by name."""
+    test_tems_gf64_every_shape_ties_and_erasures_vs_oracle(oracle, "divsalar.UNBLDPC.128.64.GF.256", 2, 3, 2)
+
+
 def test_bp_gf256_wide_ranges_and_exponent_fallback(oracle):
     """GF(256) dc=4 log-QSPA kernel on inputs that leave the narrow path: LLRs thousands of nats apart (mantissa/exponent
     path), and vectors with three near-top symbols over a floor at -4000, for which the two-entry estimate of the output
