@@ -21,14 +21,14 @@ constexpr int Q = 64, P = 6, DC = 4;
 
 struct __attribute__((aligned(16))) Cand { double u; int q; int pad; };
 
-// smaller cost wins, equal cost: smaller path code (= earlier in the reference's enumeration order)
+// smaller cost wins, equal cost: smaller path code (= earlier in the reference's enumeration order): the lexicographic
+// comparison as mask arithmetic (three compares, the AND / OR on the scalar unit), then one select for the code; the cost
+// itself is the plain minimum either way
 __device__ __forceinline__ void relax(double &bv, unsigned &bc, double val, unsigned code)
 {
-	const bool lt = val < bv;
-	bv = lt ? val : bv;
-	bc = lt ? code : bc;
-	const unsigned cm = code < bc ? code : bc;
-	bc = (val == bv) ? cm : bc;
+	const bool take = (val < bv) | ((val == bv) & (code < bc));
+	bc = take ? code : bc;
+	bv = val < bv ? val : bv;
 }
 
 __device__ __forceinline__ double pick(const double (&u)[DC], int k)
