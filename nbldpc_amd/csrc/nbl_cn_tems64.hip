@@ -28,7 +28,7 @@ __device__ __forceinline__ void relax(double &bv, unsigned &bc, double val, unsi
 {
 	const bool take = (val < bv) | ((val == bv) & (code < bc));
 	bc = take ? code : bc;
-	bv = val < bv ? val : bv;
+	bv = __builtin_fmin(bv, val);
 }
 
 __device__ __forceinline__ double pick(const double (&u)[DC], int k)
@@ -42,10 +42,14 @@ template <bool FUSED, int NC>
 __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	__shared__ double dU[DC][Q];                            // delta-domain trellis (:1814-1834)
-	__shared__ double Lc[DC][Q];                            // extrinsic minima of every output edge (:1075-1102)
-	__shared__ __attribute__((aligned(16))) double2 Sv[Q];  // cost of layers 1, 2 of every check sum before the current column
-	__shared__ uint2 Sc[Q];                                 // their path codes
-	__shared__ __attribute__((aligned(16))) Cand cl[DC][Q + 4];
+	// one phased region: during the dynamic programme the predecessor states and the candidate list, afterwards the extrinsic
+	// minima of the four outputs (4.7 KB of LDS per wave in all: the register count, not LDS, sets the waves per SIMD)
+	__shared__ __attribute__((aligned(16))) char phased[Q * 16 + Q * 8 + (Q + 4) * 16];
+	double2 *const Sv = (double2 *)phased;                  // [Q] cost of layers 1, 2 of every check sum before the current column
+	uint2 *const Sc = (uint2 *)(phased + Q * 16);           // [Q] their path codes
+	Cand *const cl = (Cand *)(phased + Q * 16 + Q * 8);     // [Q + 4] candidates of the column being folded
+	double (*const Lc)[Q] = (double (*)[Q])phased;          // [DC][Q] extrinsic minima of every output edge (:1075-1102), after the DP
+	static_assert(sizeof(phased) >= DC * Q * 8, "Lc must fit the phased region");
 	const int lane = lane_id();
 	const int b = blockIdx.x / g.M, m = blockIdx.x % g.M;
 	if (!r.fixed_iters && w.done[b]) return;
@@ -156,29 +160,29 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 		o0 = (rank == 0) ? d : o0;
 		o1 = (rank == 1) ? d : o1;
 	}
-	// deviation candidates per column: non-zero symbols only (symbol 0 = "no deviation"), ascending symbol order
-	int n4[DC];
-#pragma unroll
-	for (int d = 0; d < DC; d++) {
+	// deviation candidates of column d: non-zero symbols only (symbol 0 = "no deviation"), ascending symbol order, padded to a
+	// multiple of four with entries that can never win; returns the padded count
+	auto build_candidates = [&](int d) {
 		const bool c = ((mask >> d) & 1) && lane > 0;
 		const uint64_t bal = __ballot(c);
 		const int n = uniform(__builtin_popcountll(bal));
 		if (c) {
 			Cand e;
-			e.u = u[d];
+			e.u = pick(u, d);
 			e.q = lane;
 			e.pad = 0;
-			cl[d][prefix_count(bal)] = e;
+			cl[prefix_count(bal)] = e;
 		}
-		n4[d] = (n + 3) & ~3;
-		if (lane < 4 && n + lane < n4[d]) { // pad to a multiple of four with entries that can never win
+		const int n4 = (n + 3) & ~3;
+		if (lane < 4 && n + lane < n4) {
 			Cand e;
 			e.u = __builtin_huge_val();
 			e.q = 0;
 			e.pad = 0;
-			cl[d][n + lane] = e;
+			cl[n + lane] = e;
 		}
-	}
+		return n4;
+	};
 
 	// ---- 3. min-plus dynamic programme over the columns; v[l], c[l] = best path with exactly l deviating columns -----------
 	const double INF = __builtin_huge_val();
@@ -190,12 +194,13 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 		const int sh = P * (DC - 1 - d); // digit of column d in the path code
 		Sv[lane] = make_double2(v1, v2);
 		Sc[lane] = make_uint2(c1, c2);
+		const int n4d = (nc >= 2) ? build_candidates(d) : 0;
 		__syncthreads();
 		if (nc >= 2) {
-			for (int k = 0; k < n4[d]; k += 4) {
+			for (int k = 0; k < n4d; k += 4) {
 				Cand e[4];
 #pragma unroll
-				for (int t = 0; t < 4; t++) e[t] = cl[d][k + t]; // LDS broadcast
+				for (int t = 0; t < 4; t++) e[t] = cl[k + t]; // LDS broadcast
 #pragma unroll
 				for (int t = 0; t < 4; t++) {
 					const double2 sv = Sv[lane ^ e[t].q];
