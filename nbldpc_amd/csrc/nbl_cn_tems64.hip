@@ -19,7 +19,7 @@ namespace {
 
 constexpr int Q = 64, P = 6, DC = 4;
 
-struct __attribute__((aligned(16))) Cand { double u; int q; int pad; };
+struct __attribute__((aligned(16))) Cand { double u; int q16; unsigned dig; }; // q16 = 16 q: byte-offset XOR of the state gather; dig = q << digit shift
 
 // smaller cost wins, equal cost: smaller path code (= earlier in the reference's enumeration order): the lexicographic
 // comparison as mask arithmetic (three compares, the AND / OR on the scalar unit), then one select for the code; the cost
@@ -132,15 +132,13 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 			const uint64_t top = __ballot(v == mx);
 			arg = top ? __builtin_ctzll(top) : 0;
 		}
-		GfMul<Q> mh;
-		mh.init(g.c_h[c0 + d], g.poly, lane);
-		int bd = 0;
-#pragma unroll
-		for (int k = 0; k < P; k++) bd ^= ((arg >> k) & 1) ? mh.basis[k] : 0; // beta_d = h * argmax
-		bd = uniform(bd);
+		// products with the edge coefficient from the 4 KB multiplication table (L1 / scalar-cache resident) instead of GF(2)-linear
+		// arithmetic in registers: h * lane per lane, h * argmax for the wave
+		const uint8_t *mrow = g.mul + (size_t)g.c_h[c0 + d] * Q;
+		const int bd = uniform((int)mrow[arg]);                                // beta_d = h * argmax
 		beta[d] = bd;
 		syn ^= bd;
-		hmul[d] = mh.at_slot(0);
+		hmul[d] = (int)mrow[lane];
 		dU[d][hmul[d] ^ bd] = mx - v; // dU[d][h a ^ beta] = Lmax - L(a), L(0) = 0 (:1826-1831)
 	}
 	__syncthreads();
@@ -169,16 +167,16 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 		if (c) {
 			Cand e;
 			e.u = pick(u, d);
-			e.q = lane;
-			e.pad = 0;
+			e.q16 = lane << 4;
+			e.dig = (unsigned)lane << (P * (DC - 1 - d));
 			cl[prefix_count(bal)] = e;
 		}
 		const int n4 = (n + 3) & ~3;
 		if (lane < 4 && n + lane < n4) {
 			Cand e;
 			e.u = __builtin_huge_val();
-			e.q = 0;
-			e.pad = 0;
+			e.q16 = 0;
+			e.dig = 0;
 			cl[n + lane] = e;
 		}
 		return n4;
@@ -186,6 +184,7 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 
 	// ---- 3. min-plus dynamic programme over the columns; v[l], c[l] = best path with exactly l deviating columns -----------
 	const double INF = __builtin_huge_val();
+	const int lane16 = lane << 4;
 	double v1 = INF, v2 = INF, v3 = INF;
 	unsigned c1 = 0, c2 = 0, c3 = 0;
 	if (((mask >> 0) & 1) && lane > 0) { v1 = u[0]; c1 = (unsigned)lane << (P * (DC - 1)); }
@@ -203,11 +202,11 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 				for (int t = 0; t < 4; t++) e[t] = cl[k + t]; // LDS broadcast
 #pragma unroll
 				for (int t = 0; t < 4; t++) {
-					const double2 sv = Sv[lane ^ e[t].q];
-					const uint2 sc = Sc[lane ^ e[t].q];
-					const unsigned dig = (unsigned)e[t].q << sh;
-					relax(v2, c2, sv.x + e[t].u, sc.x + dig);
-					if (d >= 2 && nc >= 3) relax(v3, c3, sv.y + e[t].u, sc.y + dig);
+					const int off = lane16 ^ e[t].q16;
+					const double2 sv = *(const double2 *)((const char *)Sv + off);
+					const uint2 sc = *(const uint2 *)((const char *)Sc + (off >> 1));
+					relax(v2, c2, sv.x + e[t].u, sc.x + e[t].dig);
+					if (d >= 2 && nc >= 3) relax(v3, c3, sv.y + e[t].u, sc.y + e[t].dig);
 				}
 			}
 		}
