@@ -597,7 +597,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	// NP max-plus gather convolutions over ONE list: acc[p][s] = max_k  P_p[s ^ t_k] + v_k, P_p = B0 + p * Q
 	auto gather_conv = [&](int jc, auto np_tag, double (&acc)[decltype(np_tag)::value][4]) {
 		constexpr int NP = decltype(np_tag)::value;
-		constexpr int UN = (NP == 1) ? 4 : 2; // entries per trip
+		constexpr int UN = 4; // entries per trip (twelve 16-byte gathers in flight in the three-way loop)
 		const char *Pb = (const char *)B0;
 		// entries [0, n0): even symbols, the lane's slot pairs line up; [n0, NM): odd symbols, the pairs are swapped.  UN entries
 		// per trip, then the remainder one by one (no padding entries: every trip is real work)

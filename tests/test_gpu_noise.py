@@ -89,3 +89,36 @@ def test_two_phase_channel_overlaps_the_decode(tmp_path):
     with pytest.raises(nb.NblError):
         dec.decode_resident(0, sigma, P // 2)   # the slot holds a batch of another size
     dec.close()
+
+
+def test_channel_entry_points_edge_cases(tmp_path):
+    """Ragged / tiny batches, an empty batch, and the error paths of the device-side channel."""
+    import ctypes as C
+    P = 7
+    code, points, L, q = _setup(tmp_path, "divsalar.UNBLDPC.128.64.GF.256", "BPSK", 2, P, 5, ems_nm=16, ems_nc=3)
+    rx, txi, state, sigma = hostlib.channel(str(tmp_path), 2.5, 1, L, P)
+    dec = nb.Decoder(code, nb.METHOD_EMS, 10, ems_nm=16, ems_nc=3)
+    # the channel needs the constellation points, also for BPSK
+    dec.set_demodulator(2, L, np.arange(L))
+    with pytest.raises(nb.NblError) as e:
+        dec.decode_noise(txi, state, sigma)
+    assert e.value.status == -1 and "constellation" in str(e.value)
+    dec.set_demodulator(2, L, np.arange(L), points)
+    ref = dec.decode_samples(rx, sigma)
+    for B in (1, 3, P):                               # batches far below one wave's worth of work, odd sizes
+        got = dec.decode_noise(txi[:B], state[:B], sigma)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b[:B]), B
+        r2, _ = dec.channel(txi[:B], state[:B], sigma)
+        assert np.array_equal(r2.view(np.uint64), rx[:B].view(np.uint64))
+    out, conv, it = dec.decode_noise(txi[:0], state[:0], sigma)   # empty batch: nothing to do, no error
+    assert out.shape == (0, code.N)
+    with pytest.raises(nb.NblError):
+        dec.decode_noise(txi, state, -1.0)            # sigma must be positive
+    lib = nb.load_library()
+    lib.nbl_rand_advance.argtypes = [C.c_void_p, C.c_uint64]
+    lib.nbl_rand_advance.restype = None
+    st = state[0].copy()
+    lib.nbl_rand_advance(st.ctypes.data, 0)
+    assert np.array_equal(st, state[0])               # zero draws: unchanged
+    dec.close()
