@@ -65,6 +65,8 @@ struct nbl_decoder {
 	struct GraphKey { const void *lin, *lch, *v2c, *c2v, *alt, *post; int B, record, generic, fused; };
 	GraphKey gkey{};
 	std::vector<hipGraphExec_t> gexec; // index = window number
+	int *d_active = nullptr;           // [cap] active list (early exit, batches of NBL_COMPACT_MIN codewords or more)
+	bool use_compact = true;           // NBL_COMPACT=0 switches it off
 	bool use_graph = false;            // opt-in (NBL_GRAPH=1): measured gain is nil, see DESIGN.md section 7
 	int force_generic = 0;      // debug: 1 = always the generic kernels, 2 = specialised kernels but no VN/CN fusion
 	bool profiling = false;
@@ -113,7 +115,9 @@ static void drop_graphs(nbl_decoder *d)
 static void free_workspace(nbl_decoder *d)
 {
 	drop_graphs(d);
-	void *ptrs[] = {d->w.Lch, d->w.v2c, d->w.c2v, d->w.post, d->w.dec, d->w.out, d->w.iters, d->w.done, d->d_Lin, d->d_conv8, d->c2v_alt, d->w.edge_dec};
+	void *ptrs[] = {d->w.Lch, d->w.v2c, d->w.c2v, d->w.post, d->w.dec, d->w.out, d->w.iters, d->w.done, d->d_Lin, d->d_conv8, d->c2v_alt, d->w.edge_dec, d->d_active};
+	d->d_active = nullptr;
+	d->w.active = nullptr;
 	d->c2v_alt = nullptr;
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
@@ -159,6 +163,7 @@ static nbl_status ensure_workspace(nbl_decoder *d, int B)
 	HIP_TRY(d, alloc((void **)&d->w.out, (size_t)cap * N * 4));
 	HIP_TRY(d, alloc((void **)&d->w.iters, (size_t)cap * 4));
 	HIP_TRY(d, alloc((void **)&d->w.done, (size_t)cap));
+	HIP_TRY(d, alloc((void **)&d->d_active, (size_t)cap * 4));
 	d->cap = cap;
 	d->ws_bytes = bytes;
 	return NBL_OK;
@@ -267,6 +272,7 @@ extern "C" nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_m
 	if (hipSetDevice(device) != hipSuccess) return fail_create(d, NBL_ERR_HIP, "hipSetDevice failed");
 	if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) return fail_create(d, NBL_ERR_HIP, "hipStreamCreate failed");
 	if (const char *e = getenv("NBL_GRAPH")) d->use_graph = atoi(e) != 0;
+	if (const char *e = getenv("NBL_COMPACT")) d->use_compact = atoi(e) != 0;
 	d->g.N = N; d->g.M = M; d->g.E = E; d->g.q = q; d->g.p = p; d->g.poly = poly; d->g.maxdc = maxdc; d->g.maxdv = maxdv;
 	std::vector<uint8_t> mul8((size_t)q * q);
 	for (size_t i = 0; i < mul8.size(); i++) mul8[i] = (uint8_t)gf_mul[i];
@@ -298,6 +304,7 @@ extern "C" nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_m
 	if (hipMalloc(&cnt, 16) != hipSuccess) return fail_create(d, NBL_ERR_NOMEM, "hipMalloc failed");
 	d->graph_allocs.push_back(cnt);
 	d->w.n_done = (int *)cnt;
+	d->w.n_act = (int *)cnt + 1;
 	if (hipEventCreate(&d->ev[0]) != hipSuccess || hipEventCreate(&d->ev[1]) != hipSuccess) return fail_create(d, NBL_ERR_HIP, "hipEventCreate failed");
 	if (params->max_batch > 0 && (st = ensure_workspace(d, params->max_batch))) return fail_create(d, st, "");
 	*out = d;
@@ -538,23 +545,34 @@ static nbl_status run_iterations(nbl_decoder *d, const double *d_Lin, int B, hip
 	// Early exit without idling the GPU: window w+1 is queued BEFORE the host looks at the count of converged codewords that
 	// window w left behind (read back through pinned memory behind an event).  If everything had converged, the extra window
 	// finds every codeword frozen and its kernels return at once; outputs, flags and iteration counts are unaffected.
+	// Large batches: after every window the device rebuilds the list of codewords still iterating, and the grids of the next
+	// windows cover that list -- sized by the newest converged count the host has seen, an upper bound of the list's length --
+	// instead of the whole batch (most codewords of a waterfall batch are done long before the stragglers).
+	const bool compact = polling && d->use_compact && !d->use_graph && B >= 1024;
+	d->w.active = nullptr;
 	int pending = -1; // parity of the read-back that has not been looked at yet
 	for (int it_lo = 1, widx = 0; it_lo <= p.max_iter; it_lo += wlen, widx++) {
 		const int it_hi = (it_lo + wlen - 1 < p.max_iter) ? it_lo + wlen - 1 : p.max_iter;
 		nbl_status s = run_window(c, widx, it_lo, it_hi, st);
-		if (s) return s;
+		if (s) { d->w.active = nullptr; return s; }
 		last_it = it_hi;
 		if (polling) {
 			const int par = widx & 1;
 			HIP_TRY(d, hipMemcpyAsync(&d->h_ndone[par], d->w.n_done, sizeof(int), hipMemcpyDeviceToHost, st));
 			HIP_TRY(d, hipEventRecord(d->ev[par], st));
+			if (compact) {
+				HIP_TRY(d, nbl_launch_compact(d->w.done, B, d->d_active, (int *)d->w.n_act, st));
+				d->w.active = d->d_active;
+			}
 			if (pending >= 0) {
 				HIP_TRY(d, hipEventSynchronize(d->ev[pending]));
 				if (d->h_ndone[pending] >= B) break;
+				if (compact) c.r.B = B - d->h_ndone[pending];
 			}
 			pending = par;
 		}
 	}
+	d->w.active = nullptr;
 	if (polling) HIP_TRY(d, hipStreamSynchronize(st));
 	if (c.fused && last_it > 0) d->last_c2v = (last_it & 1) ? c.bufB : c.bufA;
 	if (d->profiling && c.nev > 0) {

@@ -180,7 +180,8 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 	__shared__ __attribute__((aligned(16))) double smem[4 * Q]; // 8 KB: four permutation buffers, then the operands
 	const int lane = lane_id();
 	const int bid = blockIdx.x;
-	const int b = bid / g.M, m = bid % g.M;
+	const int b = nbl_codeword(w, r, bid / g.M), m = bid % g.M;
+	if (b < 0) return;
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m];
 

@@ -264,8 +264,8 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	// a codeword are given to ONE XCD, so the second read of every L_ch / c2v vector (each is used by two checks) can hit
 	// that L2.  Speed only: nothing depends on the placement.
 	const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-	const int m = idx % g.M, b = (idx / g.M) * 8 + xcd;
-	if (b >= r.B) return;
+	const int m = idx % g.M, b = nbl_codeword(w, r, (idx / g.M) * 8 + xcd);
+	if (b < 0) return;
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m];
 

@@ -29,7 +29,8 @@ __global__ __launch_bounds__(64) void cn_tems_kernel(NblGraphDev g, NblWork w, N
 	constexpr int NS = Fld<Q>::NS;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int lane = lane_id();
-	const int b = blockIdx.x / g.M, m = blockIdx.x % g.M;
+	const int b = nbl_codeword(w, r, blockIdx.x / g.M), m = blockIdx.x % g.M;
+	if (b < 0) return;
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m], dc = g.coff[m + 1] - c0;
 	const int nr = r.nr, nc = r.nc, layers = nc + 1, mdc = g.maxdc;
@@ -245,7 +246,8 @@ __global__ __launch_bounds__(64) void cn_tems_fast_kernel(NblGraphDev g, NblWork
 	constexpr int NS = Fld<Q>::NS;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int lane = lane_id();
-	const int b = blockIdx.x / g.M, m = blockIdx.x % g.M;
+	const int b = nbl_codeword(w, r, blockIdx.x / g.M), m = blockIdx.x % g.M;
+	if (b < 0) return;
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m], dc = g.coff[m + 1] - c0;
 	const int nr = r.nr, nc = r.nc, layers = nc + 1, mdc = g.maxdc;

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 	double (*Lc)[Q] = (double (*)[Q])(lds + DC * Q * 8);   // [2][Q] extrinsic minima of two output edges at a time (:1075-1102)
 
 	const int lane = lane_id();
-	const int b = blockIdx.x / g.M, m = blockIdx.x % g.M;
+	const int b = nbl_codeword(w, r, blockIdx.x / g.M), m = blockIdx.x % g.M;
+	if (b < 0) return;
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m];
 	const int nr = r.nr;

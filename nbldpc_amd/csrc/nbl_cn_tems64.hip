@@ -51,7 +51,8 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 	double (*const Lc)[Q] = (double (*)[Q])phased;          // [DC][Q] extrinsic minima of every output edge (:1075-1102), after the DP
 	static_assert(sizeof(phased) >= DC * Q * 8, "Lc must fit the phased region");
 	const int lane = lane_id();
-	const int b = blockIdx.x / g.M, m = blockIdx.x % g.M;
+	const int b = nbl_codeword(w, r, blockIdx.x / g.M), m = blockIdx.x % g.M;
+	if (b < 0) return;
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m];
 	const int nr = r.nr;

@@ -38,11 +38,15 @@ struct NblWork {
 	int *edge_dec;                  // fused damped iterations (T-EMS, BP): hard decision of every v2c vector of the previous iteration
 	uint8_t *done;
 	int *n_done;                    // device counter of converged codewords
+	const int *active;              // early exit, large batches: codewords still iterating, ascending, rebuilt after every window of
+	                                // iterations (NULL = every codeword has its own slot); grids then cover r.B SLOTS, not codewords
+	const int *n_act;               // number of valid entries of `active`
 	unsigned long long *stamps;     // [16] debug: per-section cycle sums of the check-node kernel (NULL = off)
 };
 
 struct NblRun {
-	int B, iter, fixed_iters;
+	int B;                          // codeword slots the grid covers (= batch size unless w.active is set, then an upper bound of *w.n_act)
+	int iter, fixed_iters;
 	int nm, nc, nr;
 	double factor, offset;
 	double damp_old, damp_new;

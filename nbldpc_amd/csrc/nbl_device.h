@@ -14,6 +14,15 @@ template <int Q> struct Fld {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// codeword of grid slot `slot` (wave-uniform), -1 = nothing to do.  With the active list (early exit on large batches) the grid
+// only covers the codewords that were still iterating after the previous window.
+__device__ __forceinline__ int nbl_codeword(const NblWork &w, const NblRun &r, int slot)
+{
+	if (slot >= r.B) return -1;
+	if (!w.active) return slot;
+	return slot < *w.n_act ? w.active[slot] : -1;
+}
+
 // v_max_f64 without the canonicalising pre-max hipcc adds in front of fmax() on loaded values
 __device__ __forceinline__ double dmax(double a, double b)
 {

@@ -8,6 +8,7 @@ hipError_t nbl_launch_demod(const double *d_rx, int L, double sigma, int mod_ord
                             const NblGraphDev &g, const NblWork &w, int B, hipStream_t st);
 hipError_t nbl_launch_vn(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool damp, hipStream_t st);
 hipError_t nbl_launch_syn(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);
+hipError_t nbl_launch_compact(const uint8_t *done, int B, int *active, int *n_act, hipStream_t st);
 hipError_t nbl_launch_cn_ems(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);
 hipError_t nbl_launch_unpad(const double *src, double *dst, const int *map, int rows, int q, hipStream_t st);
 size_t nbl_ems_lds_bytes(const NblGraphDev &g, int nm, int layers);

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void vn_kernel(NblGraphDev g, NblWork w, NblRu
 	const int lane = lane_id();
 	const long long node = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	if (node >= (long long)r.B * g.N) return;
-	const int b = (int)(node / g.N), n = (int)(node % g.N);
+	const int b = nbl_codeword(w, r, (int)(node / g.N)), n = (int)(node % g.N);
+	if (b < 0) return;
 	if (!r.fixed_iters && w.done[b]) return;
 
 	const int e0 = g.voff[n], dv = g.voff[n + 1] - e0;
@@ -164,8 +165,8 @@ __global__ __launch_bounds__(256) void vn_kernel(NblGraphDev g, NblWork w, NblRu
 __global__ __launch_bounds__(256) void syn_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	const int lane = lane_id();
-	const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	if (b >= r.B) return;
+	const int b = nbl_codeword(w, r, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+	if (b < 0) return;
 	const int frozen = w.done[b];
 	if (frozen) return;
 	const int *dec = w.dec + (size_t)b * g.N;
@@ -286,7 +287,8 @@ __global__ __launch_bounds__(64) void cn_ems_kernel(NblGraphDev g, NblWork w, Nb
 	constexpr int NS = Fld<Q>::NS;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int lane = lane_id();
-	const int b = blockIdx.x / g.M, m = blockIdx.x % g.M;
+	const int b = nbl_codeword(w, r, blockIdx.x / g.M), m = blockIdx.x % g.M;
+	if (b < 0) return;
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m], dc = g.coff[m + 1] - c0;
 	const int nm = r.nm;
@@ -565,6 +567,43 @@ hipError_t nbl_launch_vn(const NblGraphDev &g, const NblWork &w, const NblRun &r
 	dim3 grid((unsigned)((nodes + 3) / 4)), block(256);
 	if (damp) { NBL_DISPATCH_Q(g.q, vn_kernel<QQ, true><<<grid, block, 0, st>>>(g, w, r)) }
 	else { NBL_DISPATCH_Q(g.q, vn_kernel<QQ, false><<<grid, block, 0, st>>>(g, w, r)) }
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// early exit on large batches: the list of codewords that are still iterating, ascending (one workgroup; B is a few
+// thousand).  Grids of the next window of iterations cover this list instead of the whole batch.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void compact_kernel(const uint8_t *__restrict__ done, int B, int *__restrict__ active, int *__restrict__ n_act)
+{
+	__shared__ int wsum[16];
+	__shared__ int base;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	if (threadIdx.x == 0) base = 0;
+	__syncthreads();
+	for (int b0 = 0; b0 < B; b0 += 1024) {
+		const int b = b0 + (int)threadIdx.x;
+		const bool live = b < B && !done[b];
+		const uint64_t m = __ballot(live);
+		if (lane == 0) wsum[wv] = __builtin_popcountll(m);
+		__syncthreads();
+		int before = base;
+		for (int k = 0; k < wv; k++) before += wsum[k];
+		if (live) active[before + prefix_count(m)] = b;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			int t = 0;
+			for (int k = 0; k < 16; k++) t += wsum[k];
+			base += t;
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) *n_act = base;
+}
+
+hipError_t nbl_launch_compact(const uint8_t *done, int B, int *active, int *n_act, hipStream_t st)
+{
+	hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, st, done, B, active, n_act);
 	return hipGetLastError();
 }
 
