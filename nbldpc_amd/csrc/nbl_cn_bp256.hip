@@ -33,8 +33,31 @@ struct XVec {      // probabilities of the lane's four symbols relative to the v
 	int e[4];      // exponent, <= 0, clamped at -1e9
 	double mx;     // wave-uniform: the maximum that was divided out (log domain)
 	double rng;    // wave-uniform: max - min (log domain)
-	int tsym[TOPK], te[TOPK]; // wave-uniform: the TOPK most likely symbols and their exponents
 };
+
+// the TOPK largest entries of a vector and their exponents, wave-uniform (seeds of the per-output exponent estimate of the wide
+// path; computed only there -- the narrow path, which is what runs at every realistic operating point, has no use for them);
+// ties in any order
+struct TopK { int tsym[TOPK], te[TOPK]; };
+__device__ __forceinline__ TopK top_entries(const XVec &r, int lane)
+{
+	TopK t;
+	int taken = 0;
+#pragma unroll
+	for (int k = 0; k < TOPK; k++) {
+		int key = -1;
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int ki = ((max(r.e[i], -(1 << 22)) + (1 << 22)) << 8) | (4 * lane + i);
+			key = ((taken >> i) & 1) ? key : max(key, ki);
+		}
+		const int best = wave_imax(key);
+		t.tsym[k] = best & 255;
+		t.te[k] = (best >> 8) - (1 << 22);
+		if (key == best) taken |= 1 << (best & 3);
+	}
+	return t;
+}
 
 __device__ __forceinline__ XVec to_xvec(const double (&L)[4], int lane)
 {
@@ -48,21 +71,6 @@ __device__ __forceinline__ XVec to_xvec(const double (&L)[4], int lane)
 		const double f = floor(y);
 		r.m[i] = exp2(y - f);
 		r.e[i] = (int)f;
-	}
-	// the TOPK largest entries (seeds of the per-output exponent estimate in lse_conv); ties in any order
-	int taken = 0;
-#pragma unroll
-	for (int k = 0; k < TOPK; k++) {
-		int key = -1;
-#pragma unroll
-		for (int i = 0; i < 4; i++) {
-			const int ki = ((max(r.e[i], -(1 << 22)) + (1 << 22)) << 8) | (4 * lane + i);
-			key = ((taken >> i) & 1) ? key : max(key, ki);
-		}
-		const int best = wave_imax(key);
-		r.tsym[k] = best & 255;
-		r.te[k] = (best >> 8) - (1 << 22);
-		if (key == best) taken |= 1 << (best & 3);
 	}
 	return r;
 }
@@ -119,12 +127,13 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 		// exponent is taken (integer max-plus pass) and the sum is redone.
 		int ex[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
 		const int *AeI = (const int *)s.Ae, *BeI = (const int *)s.Be;
+		const TopK At = top_entries(A, lane), Bt = top_entries(B, lane);
 #pragma unroll
 		for (int k = 0; k < TOPK; k++) {
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
 				const int z = 4 * lane + i;
-				ex[i] = max(ex[i], max(A.te[k] + BeI[z ^ A.tsym[k]], B.te[k] + AeI[z ^ B.tsym[k]]));
+				ex[i] = max(ex[i], max(At.te[k] + BeI[z ^ At.tsym[k]], Bt.te[k] + AeI[z ^ Bt.tsym[k]]));
 			}
 		}
 		double acc[4];
@@ -174,6 +183,54 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 	__syncthreads(); // operands are rewritten by the next convolution
 }
 
+// Two convolutions that share their first operand, A [+] B1 and A [+] B2, when both are narrow: one loop, the broadcast reads of
+// A serve both (the LDS port is what the plain-double path saturates: 24 instead of 32 port cycles per 32 FMAs).  Same terms and
+// the same accumulation order as two lse_conv calls.  Returns false (nothing done) when either convolution is wide.
+__device__ __forceinline__ bool lse_conv_pair(const XVec &A, const XVec &B1, const XVec &B2, double (&out1)[4], double (&out2)[4], const Lds &s,
+                                              int lane, unsigned long long *stamps)
+{
+	constexpr int SH = 500;
+	if (!(fmin(A.rng, B1.rng) < 1000.0 && fmin(A.rng, B2.rng) < 1000.0)) return false; // wave-uniform
+#ifdef NBL_EMS_STAMPS
+	if (stamps && lane == 0) atomicAdd(&stamps[0], 2ull);
+#endif
+	double2 *const Cm01 = (double2 *)s.Ae, *const Cm23 = Cm01 + 64; // the exponent arrays are idle on the narrow path
+	s.Am01[lane] = make_double2(ldexp(A.m[0], A.e[0] + SH), ldexp(A.m[1], A.e[1] + SH));
+	s.Am23[lane] = make_double2(ldexp(A.m[2], A.e[2] + SH), ldexp(A.m[3], A.e[3] + SH));
+	s.Bm01[lane] = make_double2(ldexp(B1.m[0], B1.e[0] + SH), ldexp(B1.m[1], B1.e[1] + SH));
+	s.Bm23[lane] = make_double2(ldexp(B1.m[2], B1.e[2] + SH), ldexp(B1.m[3], B1.e[3] + SH));
+	Cm01[lane] = make_double2(ldexp(B2.m[0], B2.e[0] + SH), ldexp(B2.m[1], B2.e[1] + SH));
+	Cm23[lane] = make_double2(ldexp(B2.m[2], B2.e[2] + SH), ldexp(B2.m[3], B2.e[3] + SH));
+	__syncthreads();
+	double acc1[4] = {0.0, 0.0, 0.0, 0.0}, acc2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+	for (int g = 0; g < 64; g++) {
+		const double2 a01 = s.Am01[g], a23 = s.Am23[g];
+		const double2 b01 = s.Bm01[lane ^ g], b23 = s.Bm23[lane ^ g];
+		const double2 c01 = Cm01[lane ^ g], c23 = Cm23[lane ^ g];
+		const double a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y}, c[4] = {c01.x, c01.y, c23.x, c23.y};
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				acc1[i] = __fma_rn(a[j], b[i ^ j], acc1[i]);
+				acc2[i] = __fma_rn(a[j], c[i ^ j], acc2[i]);
+			}
+	}
+	double l1[4], l2[4];
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		l1[i] = ((log(acc1[i]) - (2 * SH) * LN2) + A.mx) + B1.mx;
+		l2[i] = ((log(acc2[i]) - (2 * SH) * LN2) + A.mx) + B2.mx;
+	}
+	const double n1 = read_lane_f64(l1[0], 0), n2 = read_lane_f64(l2[0], 0);
+#pragma unroll
+	for (int i = 0; i < 4; i++) { out1[i] = l1[i] - n1; out2[i] = l2[i] - n2; }
+	if (lane == 0) { out1[0] = 0.0; out2[0] = 0.0; }
+	__syncthreads();
+	return true;
+}
+
 template <bool FUSED>
 __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
@@ -209,14 +266,13 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 			const double *pl = w.Lch + ((size_t)b * g.N + n) * Q;
 			const double *pa = Cp + (size_t)g.v_cpos[e0] * Q, *pb = Cp + (size_t)g.v_cpos[e0 + 1] * Q;
 			const bool ownA = (e == e0);
-			double post[4], nv[4], ov[4];
+			double post[4], nv[4];
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
 				const int a = lane + 64 * i;
 				const double ca = pa[a], cb = pb[a];
 				post[i] = (pl[a] + ca) + cb;
 				nv[i] = post[i] - (ownA ? ca : cb);
-				ov[i] = Vd[a];
 			}
 			if (ownA) {
 				const int dec = wave_decide<4>(post, lane, Q);
@@ -226,10 +282,27 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 					for (int i = 0; i < 4; i++) w.post[((size_t)b * g.N + n) * Q + lane + 64 * i] = post[i];
 				}
 			}
-			if (wave_decide<4>(ov, lane, Q) != wave_decide<4>(nv, lane, Q)) {
+			// Damping (:730-741) compares the hard decision of the previous v2c with the new one.  The previous decision is what this
+			// stage recorded for that vector one iteration ago (w.edge_dec), so the previous v2c itself is loaded -- and reduced -- only
+			// in iteration 1 (where it is L_ch and nothing has been recorded) or when the decision moved and the blend needs it.
+			const bool first = (r.iter == 1);
+			int before;
+			if (first) {
+				double ov[4];
 #pragma unroll
-				for (int i = 0; i < 4; i++) nv[i] = __dadd_rn(__dmul_rn(r.damp_old, ov[i]), __dmul_rn(r.damp_new, nv[i]));
+				for (int i = 0; i < 4; i++) ov[i] = Vd[lane + 64 * i];
+				before = wave_decide<4>(ov, lane, Q);
+			} else before = w.edge_dec[(size_t)b * g.E + e];
+			int after = wave_decide<4>(nv, lane, Q);
+			if (before != after) {
+#pragma unroll
+				for (int i = 0; i < 4; i++) nv[i] = __dadd_rn(__dmul_rn(r.damp_old, Vd[lane + 64 * i]), __dmul_rn(r.damp_new, nv[i]));
+				double t[4];
+#pragma unroll
+				for (int i = 0; i < 4; i++) t[i] = (lane + 64 * i == 0) ? 0.0 : nv[i];
+				after = wave_decide<4>(t, lane, Q);
 			}
+			if (lane == 0) w.edge_dec[(size_t)b * g.E + e] = after;
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
 				const int a = lane + 64 * i;
@@ -277,19 +350,32 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 	lse_conv(p[0], p[1], o, s, lane, w.stamps);
 	{
 		const XVec F2 = to_xvec(o, lane);
-		lse_conv(F2, p[2], o, s, lane, w.stamps);
-		emit(o, 3);
-		lse_conv(F2, p[3], o, s, lane, w.stamps);
-		emit(o, 2);
+		double o2[4];
+		if (lse_conv_pair(F2, p[2], p[3], o, o2, s, lane, w.stamps)) {
+			emit(o, 3);
+			emit(o2, 2);
+		} else {
+			lse_conv(F2, p[2], o, s, lane, w.stamps);
+			emit(o, 3);
+			lse_conv(F2, p[3], o, s, lane, w.stamps);
+			emit(o, 2);
+		}
 	}
 	// backward: R1 = p3 [+] p2, R0 = R1 [+] p1 = output 0 (A1 == 0 case, :757-760); output 1 = p0 [+] R1
 	lse_conv(p[3], p[2], o, s, lane, w.stamps);
 	{
 		const XVec R1 = to_xvec(o, lane);
-		lse_conv(R1, p[1], o, s, lane, w.stamps);
-		emit(o, 0);
-		lse_conv(p[0], R1, o, s, lane, w.stamps);
-		emit(o, 1);
+		double o2[4];
+		// output 1 = p0 [+] R1 is taken as R1 [+] p0 here: the same products, summed in the mirrored order
+		if (lse_conv_pair(R1, p[1], p[0], o, o2, s, lane, w.stamps)) {
+			emit(o, 0);
+			emit(o2, 1);
+		} else {
+			lse_conv(R1, p[1], o, s, lane, w.stamps);
+			emit(o, 0);
+			lse_conv(p[0], R1, o, s, lane, w.stamps);
+			emit(o, 1);
+		}
 	}
 }
 
