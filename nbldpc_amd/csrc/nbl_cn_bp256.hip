@@ -62,9 +62,13 @@ __device__ __forceinline__ TopK top_entries(const XVec &r, int lane)
 __device__ __forceinline__ XVec to_xvec(const double (&L)[4], int lane)
 {
 	XVec r;
-	r.mx = wave_fmax(dmax(dmax(L[0], L[1]), dmax(L[2], L[3])));
-	const double mn = wave_fmin(dmin(dmin(L[0], L[1]), dmin(L[2], L[3])));
-	r.rng = r.mx - mn;
+	// The reference that is divided out only has to be CLOSE to the maximum (it is added back after the convolution; an entry a
+	// float ulp above it just has mantissa 1 + 1e-7), and the range only has to be an upper bound: both reductions run on
+	// order-preserving 32-bit keys of the values rounded to float (one DPP instruction per step instead of three).
+	const int kx = nbl_key32(dmax(dmax(L[0], L[1]), dmax(L[2], L[3]))), kn = nbl_key32(dmin(dmin(L[0], L[1]), dmin(L[2], L[3])));
+	r.mx = (double)nbl_unkey32(wave_imax_id(kx));
+	const double mn = (double)nbl_unkey32(-wave_imax_id(-kn));
+	r.rng = (r.mx - mn) * (1.0 + 0x1p-20) + 0x1p-100; // (covers the float rounding of both ends)
 #pragma unroll
 	for (int i = 0; i < 4; i++) {
 		const double y = dmax((L[i] - r.mx) * LOG2E, -1.0e9);
@@ -246,16 +250,20 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 	double *C = w.c2v + ((size_t)b * g.E + c0) * Q;
 
 	// inputs into the check domain: p_d[h_d a] = v2c_d[a], symbol 0 = LLR 0 (the A1 == 0 branch of LLR_BoxPlus, :1623-1632)
-	GfMul<Q> mh[4];
+	int hsym[4][4]; // h_d * a for the lane's four symbols a = lane + 64 i (from the multiplication table, L1 / L2 resident)
 #pragma unroll
 	for (int d = 0; d < 4; d++) {
 		double *Vd = V + (size_t)g.c_epos[c0 + d] * Q;
-		mh[d].init(g.c_h[c0 + d], g.poly, lane);
+		{
+			const uint8_t *mrow = g.mul + (size_t)g.c_h[c0 + d] * Q;
+#pragma unroll
+			for (int i = 0; i < 4; i++) hsym[d][i] = mrow[lane + 64 * i];
+		}
 		if (!FUSED) {
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
 				const int a = lane + 64 * i;
-				smem[d * Q + mh[d].at_slot(i)] = (a == 0) ? 0.0 : Vd[a];
+				smem[d * Q + hsym[d][i]] = (a == 0) ? 0.0 : Vd[a];
 			}
 		} else {
 			// FUSED: the variable-node pass of this iteration for this edge (NBLDPC.cpp:676-691, :718-744): post = (L_ch + c2v_0)
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 				const int a = lane + 64 * i;
 				const double x = (a == 0) ? 0.0 : nv[i];
 				V[(size_t)e * Q + a] = x;
-				smem[d * Q + mh[d].at_slot(i)] = x;
+				smem[d * Q + hsym[d][i]] = x;
 			}
 		}
 	}
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
 			const int a = lane + 64 * i;
-			Cd[a] = (a == 0) ? 0.0 : T[mh[d].at_slot(i)];
+			Cd[a] = (a == 0) ? 0.0 : T[hsym[d][i]];
 		}
 		__syncthreads();
 	};

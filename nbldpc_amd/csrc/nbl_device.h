@@ -86,6 +86,26 @@ __device__ __forceinline__ int wave_imax(int v)
 	return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Order-preserving 32-bit key of a double (rounded to float, sign-magnitude folded to two's complement) and a wave maximum of
+// such keys: with the operation's identity as the DPP `old` value hipcc folds the move into v_max_i32_dpp (six instructions).
+__device__ __forceinline__ int nbl_key32(double x)
+{
+	const int b = __float_as_int((float)x);
+	return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float nbl_unkey32(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+__device__ __forceinline__ int wave_imax_id(int x)
+{
+	constexpr int ID = (int)0x80000000;
+	x = max(x, __builtin_amdgcn_update_dpp(ID, x, 0x111, 0xF, 0xF, false));
+	x = max(x, __builtin_amdgcn_update_dpp(ID, x, 0x112, 0xF, 0xF, false));
+	x = max(x, __builtin_amdgcn_update_dpp(ID, x, 0x114, 0xF, 0xF, false));
+	x = max(x, __builtin_amdgcn_update_dpp(ID, x, 0x118, 0xF, 0xF, false));
+	x = max(x, __builtin_amdgcn_update_dpp(ID, x, 0x142, 0xA, 0xF, false));
+	x = max(x, __builtin_amdgcn_update_dpp(ID, x, 0x143, 0xC, 0xF, false));
+	return __builtin_amdgcn_readlane(x, 63);
+}
+
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ double uniform_f64(double v)
