@@ -20,6 +20,7 @@
 // hazard 3); parity is on hard decisions, flags and FER, LLRs within 1e-9 of the oracle's FP64 restatement.
 #include <hip/hip_runtime.h>
 #include "nbl_device.h"
+#include "nbl_fastmath.h"
 #include "nbl_kernels.h"
 
 namespace {
@@ -73,7 +74,7 @@ __device__ __forceinline__ XVec to_xvec(const double (&L)[4], int lane)
 	for (int i = 0; i < 4; i++) {
 		const double y = dmax((L[i] - r.mx) * LOG2E, -1.0e9);
 		const double f = floor(y);
-		r.m[i] = exp2(y - f);
+		r.m[i] = nbl_exp2_frac(y - f);
 		r.e[i] = (int)f;
 	}
 	return r;
@@ -116,7 +117,7 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 				for (int i = 0; i < 4; i++) acc[i] = __fma_rn(a[j], b[i ^ j], acc[i]);
 		}
 #pragma unroll
-		for (int i = 0; i < 4; i++) lse[i] = ((log(acc[i]) - (2 * SH) * LN2) + A.mx) + B.mx;
+		for (int i = 0; i < 4; i++) lse[i] = ((nbl_log_pos(acc[i]) - (2 * SH) * LN2) + A.mx) + B.mx;
 	} else {
 		s.Am01[lane] = make_double2(A.m[0], A.m[1]);
 		s.Am23[lane] = make_double2(A.m[2], A.m[3]);
@@ -178,7 +179,7 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 			}
 		}
 #pragma unroll
-		for (int i = 0; i < 4; i++) lse[i] = ((log(acc[i]) + (double)ex[i] * LN2) + A.mx) + B.mx;
+		for (int i = 0; i < 4; i++) lse[i] = ((nbl_log_pos(acc[i]) + (double)ex[i] * LN2) + A.mx) + B.mx;
 	}
 	const double norm = read_lane_f64(lse[0], 0); // z = 0
 #pragma unroll
@@ -224,8 +225,8 @@ __device__ __forceinline__ bool lse_conv_pair(const XVec &A, const XVec &B1, con
 	double l1[4], l2[4];
 #pragma unroll
 	for (int i = 0; i < 4; i++) {
-		l1[i] = ((log(acc1[i]) - (2 * SH) * LN2) + A.mx) + B1.mx;
-		l2[i] = ((log(acc2[i]) - (2 * SH) * LN2) + A.mx) + B2.mx;
+		l1[i] = ((nbl_log_pos(acc1[i]) - (2 * SH) * LN2) + A.mx) + B1.mx;
+		l2[i] = ((nbl_log_pos(acc2[i]) - (2 * SH) * LN2) + A.mx) + B2.mx;
 	}
 	const double n1 = read_lane_f64(l1[0], 0), n2 = read_lane_f64(l2[0], 0);
 #pragma unroll

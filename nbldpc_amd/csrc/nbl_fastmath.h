@@ -1,0 +1,69 @@
+// nbldpc_amd/csrc/nbl_fastmath.h -- short FP64 log / exp2 for the log-QSPA kernels (host + device).
+//
+// The check node needs  exp2(x), x in [0, 1)  (mantissa of a probability) and  log(a), a > 0 finite  (a sum of products) four
+// times per vector.  The device library's routines handle every special case and cost ~35 / ~60 instructions; these two do
+// the job in ~17 / ~30 with the same ~1 ulp accuracy on their (restricted) domains -- tests/test_ddmath.py measures both against
+// glibc.  Not for general use: no NaN / infinity / zero / denormal handling beyond what the kernels can produce
+// (log(+0) = -inf is kept: an all-zero sum can only come from underflow and must stay "impossible").
+#pragma once
+#include <math.h>
+#if defined(__HIPCC__)
+#define NBL_FM __host__ __device__ __forceinline__
+#else
+#define NBL_FM static inline
+#endif
+
+// 2^x for 0 <= x < 1: 2^x = sqrt(2) * e^(t ln 2), t = x - 1/2 in [-1/2, 1/2): Taylor series of degree 14 in u = t ln 2 (|u| <= 0.347)
+NBL_FM double nbl_exp2_frac(double x)
+{
+	const double u = (x - 0.5) * 0.6931471805599453094;
+	double p = 1.0 / 87178291200.0;            // 1/14!
+	p = fma(p, u, 1.0 / 6227020800.0);         // 1/13!
+	p = fma(p, u, 1.0 / 479001600.0);
+	p = fma(p, u, 1.0 / 39916800.0);
+	p = fma(p, u, 1.0 / 3628800.0);
+	p = fma(p, u, 1.0 / 362880.0);
+	p = fma(p, u, 1.0 / 40320.0);
+	p = fma(p, u, 1.0 / 5040.0);
+	p = fma(p, u, 1.0 / 720.0);
+	p = fma(p, u, 1.0 / 120.0);
+	p = fma(p, u, 1.0 / 24.0);
+	p = fma(p, u, 1.0 / 6.0);
+	p = fma(p, u, 0.5);
+	// e^u = 1 + (u + u^2 p): the small part first, then sqrt(2) = hi + lo times (1 + small) with one rounding of the large term
+	const double em1 = fma(u * u, p, u);
+	const double r = fma(1.4142135623730951455, em1, 1.4142135623730951455);
+	return fma(-9.667293313452913451e-17, 1.0 + em1, r);
+}
+
+// log(a) for finite a > 0 (log(0) = -inf): a = m 2^e with m in [3/4, 3/2); log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 1/5
+NBL_FM double nbl_log_pos(double a)
+{
+	if (a == 0.0) return -HUGE_VAL;
+	int e;
+	double m = frexp(a, &e);                   // [1/2, 1)
+	if (m < 0.75) { m *= 2.0; e -= 1; }        // [3/4, 3/2)
+	const double f = m - 1.0, d = m + 1.0;
+	// s = f / d by reciprocal + one Newton correction of the quotient (d in [1.75, 2.5])
+	const double r = 1.0 / d;
+	double s = f * r;
+	s = fma(fma(-s, d, f), r, s);
+	const double s_lo = fma(-s, d, f) * r;     // what is still missing of the quotient
+	const double z = s * s;
+	double p = 1.0 / 23.0;
+	p = fma(p, z, 1.0 / 21.0);
+	p = fma(p, z, 1.0 / 19.0);
+	p = fma(p, z, 1.0 / 17.0);
+	p = fma(p, z, 1.0 / 15.0);
+	p = fma(p, z, 1.0 / 13.0);
+	p = fma(p, z, 1.0 / 11.0);
+	p = fma(p, z, 1.0 / 9.0);
+	p = fma(p, z, 1.0 / 7.0);
+	p = fma(p, z, 1.0 / 5.0);
+	p = fma(p, z, 1.0 / 3.0);
+	// log m = 2 s + (2 s z p + 2 s_lo);  result = e ln2 (hi + lo) + log m
+	const double t = 2.0 * s;
+	const double lm = t + fma(t * z, p, 2.0 * s_lo);
+	const double ed = (double)e;
+	return fma(ed, 0.6931471805599453094, fma(ed, 2.319046813846299558e-17, lm));
+}

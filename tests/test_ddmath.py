@@ -22,3 +22,13 @@ def test_certain_values_equal_glibc(tmp_path):
             tot[k] += r[k]
     # glibc itself is not always correctly rounded (that is why the uncertain values go to the host): seen here too
     assert tot["glibc_not_rounded_log"] > 0 and tot["glibc_not_rounded_cos"] > 0
+
+
+def test_short_log_and_exp2_within_one_ulp_of_glibc(tmp_path):
+    """nbl_fastmath.h (the log / exp2 of the GF(256) log-QSPA kernel): at most one ulp from glibc on 4 M arguments of their domains
+    (exp2 on [0, 1); log on sums spanning 2000 binades and on values around 1)."""
+    exe = str(tmp_path / "fastmath_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-I", os.path.join(ROOT, "nbldpc_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "fastmath_check.cpp"), "-o", exe])
+    r = json.loads(subprocess.check_output([exe], text=True))
+    assert r["exp2_worst_ulp"] <= 1.0 and r["log_worst_ulp"] <= 1.0, r
