@@ -33,6 +33,8 @@ struct nbl_decoder {
 	bool all_dc4 = false;       // every check has degree 4
 	bool all_dv2 = false;       // every variable has degree 2
 	double *c2v_alt = nullptr;  // second c2v buffer of the fused EMS iteration (flooding schedule -> double buffer)
+	double *c2v_zero = nullptr; // fused iterations: the all-zero c2v of iteration 0, written once when the workspace is made and only
+	                            // ever read (iteration 1 reads it instead of a buffer that would have to be cleared on every call)
 	const double *last_c2v = nullptr;
 	bool last_fused = false;    // the last decode ran fused iterations (nbl_read_state picks the c2v buffer per codeword)
 	// device-side demodulator (nbl_set_demodulator)
@@ -115,7 +117,8 @@ static void drop_graphs(nbl_decoder *d)
 static void free_workspace(nbl_decoder *d)
 {
 	drop_graphs(d);
-	void *ptrs[] = {d->w.Lch, d->w.v2c, d->w.c2v, d->w.post, d->w.dec, d->w.out, d->w.iters, d->w.done, d->d_Lin, d->d_conv8, d->c2v_alt, d->w.edge_dec, d->d_active};
+	void *ptrs[] = {d->w.Lch, d->w.v2c, d->w.c2v, d->w.post, d->w.dec, d->w.out, d->w.iters, d->w.done, d->d_Lin, d->d_conv8, d->c2v_alt, d->w.edge_dec, d->d_active, d->c2v_zero};
+	d->c2v_zero = nullptr;
 	d->d_active = nullptr;
 	d->w.active = nullptr;
 	d->c2v_alt = nullptr;
@@ -156,7 +159,11 @@ static nbl_status ensure_workspace(nbl_decoder *d, int B)
 	HIP_TRY(d, alloc((void **)&d->w.Lch, (size_t)cap * N * q * 8));
 	if (want_v2c) HIP_TRY(d, alloc((void **)&d->w.v2c, (size_t)cap * E * q * 8));
 	HIP_TRY(d, alloc((void **)&d->w.c2v, (size_t)cap * E * q * 8));
-	if (fused_shape(d)) HIP_TRY(d, alloc((void **)&d->c2v_alt, (size_t)cap * E * q * 8));
+	if (fused_shape(d)) {
+		HIP_TRY(d, alloc((void **)&d->c2v_alt, (size_t)cap * E * q * 8));
+		HIP_TRY(d, alloc((void **)&d->c2v_zero, (size_t)cap * E * q * 8));
+		HIP_TRY(d, hipMemset(d->c2v_zero, 0, (size_t)cap * E * q * 8));
+	}
 	if (d->record_state) HIP_TRY(d, alloc((void **)&d->w.post, (size_t)cap * N * q * 8));
 	HIP_TRY(d, alloc((void **)&d->w.dec, (size_t)cap * N * 4));
 	if (d->prm.method != NBL_METHOD_EMS) HIP_TRY(d, alloc((void **)&d->w.edge_dec, (size_t)cap * E * 4));
@@ -427,6 +434,7 @@ struct IterCtx {
 	NblRun r;
 	bool damp, fused;
 	double *bufA, *bufB;
+	const double *zeros = nullptr; // stands in for bufA in iteration 1 (then bufA needs no clearing)
 	// profiling: one event after every launch on the launch stream; phase time = sum of the gaps it closes
 	size_t nev = 0;
 	std::vector<int> tag; // 0 vn, 1 syn, 2 cn, 3 other
@@ -451,7 +459,7 @@ static nbl_status enqueue_window(IterCtx &c, int it_lo, int it_hi, hipStream_t s
 		if (c.fused) {
 			// one launch = variable-node pass + check-node pass; c2v ping-pongs between the two buffers
 			NblWork wf = d->w;
-			wf.c2v_prev = (it & 1) ? c.bufA : c.bufB;
+			wf.c2v_prev = (it == 1 && c.zeros) ? c.zeros : (it & 1) ? c.bufA : c.bufB;
 			wf.c2v = (it & 1) ? c.bufB : c.bufA;
 			wf.store_v2c = d->record_state ? 1 : 0;
 			if (p.method == NBL_METHOD_EMS) HIP_TRY(d, nbl_launch_cn_ems256(d->g, wf, c.r, true, st));
@@ -529,13 +537,14 @@ static nbl_status run_iterations(nbl_decoder *d, const double *d_Lin, int B, hip
 	c.fused = fused_shape(d) && d->force_generic == 0 && d->c2v_alt;
 	c.bufA = d->w.c2v;
 	c.bufB = d->c2v_alt;
+	c.zeros = c.fused ? d->c2v_zero : nullptr;
 	// the captured graphs hold buffer addresses and the batch size: any change drops them
 	const nbl_decoder::GraphKey key = {d_Lin, d->w.Lch, d->w.v2c, d->w.c2v, d->c2v_alt, d->w.post, B, d->record_state ? 1 : 0, d->force_generic, c.fused ? 1 : 0};
 	if (memcmp(&key, &d->gkey, sizeof key) != 0) { drop_graphs(d); d->gkey = key; }
 	HIP_TRY(d, mark(c, 3, st));
-	HIP_TRY(d, nbl_launch_init(d_Lin, d->g, d->w, B, c.damp ? 1 : 0, st));
+	HIP_TRY(d, nbl_launch_init(d_Lin, d->g, d->w, B, (c.damp ? 1 : 0) | (c.zeros ? 2 : 0), st)); // bit 1: c2v is not cleared
 	HIP_TRY(d, mark(c, 3, st));
-	d->last_c2v = c.bufA;
+	d->last_c2v = c.zeros ? c.zeros : c.bufA;
 	d->last_fused = c.fused;
 	// windows: fixed iterations or no polling -> one window; early exit -> `poll_every` iterations, then ask the device
 	const bool polling = !p.fixed_iters && p.poll_every > 0;
@@ -919,7 +928,7 @@ extern "C" nbl_status nbl_read_state(nbl_decoder *d, int32_t b, double *post, do
 			uint8_t done = 0;
 			HIP_TRY(d, hipMemcpy(&it, d->w.iters + b, sizeof it, hipMemcpyDeviceToHost));
 			HIP_TRY(d, hipMemcpy(&done, d->w.done + b, 1, hipMemcpyDeviceToHost));
-			if (done) src = ((it - 1) & 1) ? d->c2v_alt : d->w.c2v; // buffer written by iteration it-1 (it = 1: the zeroed bufA)
+			if (done) src = (it == 1 && d->c2v_zero) ? d->c2v_zero : ((it - 1) & 1) ? d->c2v_alt : d->w.c2v; // buffer written by iteration it-1 (it = 1: the zeros)
 		}
 		rc = grab(src + (size_t)b * E * q, d->d_e2c_map, E, c2v);
 	}

@@ -14,6 +14,8 @@
 // init: host/API layout [B][N][q-1] -> padded [B][N][q] with slot 0 = 0.0; clear c2v; v2c = L_ch
 // (NBLDPC.cpp:649-662 / 781-794 / 934-969)
 // ---------------------------------------------------------------------------------------------------------
+// write_v2c bit 0: also v2c = L_ch (damped methods read it); bit 1: leave c2v alone (fused iterations read the zeros of
+// iteration 0 from a buffer of their own)
 __global__ void init_kernel(const double *__restrict__ Lin, NblGraphDev g, NblWork w, int B, int write_v2c)
 {
 	const int q = g.q;
@@ -24,9 +26,10 @@ __global__ void init_kernel(const double *__restrict__ Lin, NblGraphDev g, NblWo
 		if (Lin) w.Lch[i] = a ? Lin[bn * (q - 1) + (a - 1)] : 0.0; // else: demod_kernel has already filled Lch
 	}
 	long long etotal = (long long)B * g.E * q;
-	for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < etotal; i += (long long)gridDim.x * blockDim.x)
-		w.c2v[i] = 0.0;
-	if (write_v2c) {
+	if (!(write_v2c & 2))
+		for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < etotal; i += (long long)gridDim.x * blockDim.x)
+			w.c2v[i] = 0.0;
+	if (write_v2c & 1) {
 		for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < etotal; i += (long long)gridDim.x * blockDim.x) {
 			int a = (int)(i % q);
 			long long be = i / q;
