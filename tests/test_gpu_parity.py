@@ -680,6 +680,45 @@ def test_hipgraph_replay_of_the_iteration_loop(monkeypatch, name, fixed, poll):
     dec.close()
 
 
+@pytest.mark.parametrize("code_name,cons,method,B,ebn0,iters,kw,rm,check_oracle", [
+    ("divsalar.UNBLDPC.128.64.GF.16", "BPSK", 4, 2500, 2.0, 20, dict(tems_nr=2, tems_nc=2), 1, True),     # general kernels
+    ("divsalar.UNBLDPC.128.64.GF.16", "BPSK", 1, 1025, 2.0, 20, dict(), 1, True),
+    ("divsalar.UNBLDPC.128.64.GF.256", "BPSK", 2, 3000, 2.0, 50, dict(ems_nm=16, ems_nc=3), 1, False),     # fused EMS iteration
+    ("BDS.576.288.GF.64", "GRAY_64QAM", 4, 2048, 3.0, 50, dict(tems_nr=2, tems_nc=3), 0, False),           # fused T-EMS iteration
+])
+def test_early_exit_with_active_list(tmp_path, monkeypatch, oracle, code_name, cons, method, B, ebn0, iters, kw, rm, check_oracle):
+    """Early exit on batches of 1024 codewords or more runs its grids over the list of codewords that are still iterating
+    (rebuilt on the device after every window).  Outputs, flags and iteration counts must equal those of
+    the plain path (NBL_COMPACT=0) for every frame, for odd batch sizes and poll intervals, and -- where the oracle is fast
+    enough -- the oracle's."""
+    from nbldpc_amd import hostlib
+    c = df.codes()[code_name]
+    q = c["q"]
+    hostlib.prepare_workdir(str(tmp_path), dict(gfq=q, code=code_name, method=method, max_iter=iters, parallel=B, nqam=(2 if cons == "BPSK" else q),
+                                                constellation=cons, random_msg=rm, seed=2718, **kw), code_name, cons)
+    L, tx, _, _ = hostlib.frontend(str(tmp_path), ebn0, 1, c["N"], c["N"] - c["M"], q, B)
+    code = nb.Code(code_name)
+    res = {}
+    for compact, poll in (("0", 3), ("1", 3), ("1", 1), ("1", 7)):
+        monkeypatch.setenv("NBL_COMPACT", compact)
+        dec = nb.Decoder(code, method, iters, poll_every=poll, **kw)
+        res[(compact, poll)] = dec.decode(L)
+        res[(compact, poll, "again")] = dec.decode(L)          # a second call on the same handle (state of the list must not leak)
+        dec.close()
+    ref = res[("0", 3)]
+    assert 0.05 < ref[1].mean() < 1.0
+    for key, got in res.items():
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), key
+    if check_oracle:
+        N, M, q, ev, ec, eh = df.code_edges(code_name)
+        ocode, ogf = oracle.Code(edges=(N, M, q, ev, ec, eh)), oracle.GF(q)
+        mk = lambda: oracle.Decoder(ocode, ogf, method, iters, oracle.CANONICAL, **kw)  # noqa: E731
+        o_out, o_conv, o_it = oracle.decode_batch(mk, L, nthreads=16)
+        assert np.array_equal(ref[1], o_conv) and np.array_equal(ref[2], o_it)
+        assert np.array_equal(ref[0][o_conv == 1], o_out[o_conv == 1])
+
+
 def test_device_pointer_entry_point():
     import torch
     g, meta = load_golden("cfg2_ems_u128")
