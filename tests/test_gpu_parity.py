@@ -480,7 +480,7 @@ def test_reference_semantics_at_scale(tmp_path, oracle, ebn0, B, seed):
     ("cfg4_2.5dB", "BDS.576.288.GF.64", "GRAY_64QAM", 96, 2.5, 50, dict(tems_nr=2, tems_nc=3), 0),
     ("cfg4_3.0dB", "BDS.576.288.GF.64", "GRAY_64QAM", 96, 3.0, 50, dict(tems_nr=2, tems_nc=3), 0),
     # GF(256): the literal enumeration costs ~3 core-seconds per iteration per frame -- one frame per host thread
-    ("u512_gf256_1.4dB", "divsalar.UNBLDPC.512.256.GF.256", "BPSK", 16, 1.4, 20, dict(tems_nr=2, tems_nc=3), 1),
+    ("u512_gf256_1.4dB", "divsalar.UNBLDPC.512.256.GF.256", "BPSK", 16, 1.4, 12, dict(tems_nr=2, tems_nc=3), 1),
     ("c256_gf256_3.6dB", "divsalar.CNBLDPC.256.128.GF.256", "GRAY_256QAM", 16, 3.6, 12, dict(tems_nr=3, tems_nc=3, tems_factor=1.05, tems_offset=0.02), 0),
 ])
 def test_tems_reference_semantics_at_scale(tmp_path, oracle, label, code_name, cons, B, ebn0, iters, kw, rm):
