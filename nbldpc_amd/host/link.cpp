@@ -59,6 +59,13 @@ bool CLink::Initial(const std::string &profile, const std::vector<int> &device_l
 		state_batch[slot].assign(device_noise ? (size_t)3 * sim.parallel : 0, 0);
 		L_batch[slot].assign(device_demod ? 0 : per * sim.parallel, 0.0);
 	}
+	{ // algorithmic bytes of the decode: per frame 8(q-1)N + 4N + 4, per iteration 8(q-1)(N + 4E + D E), D = 1 with damping
+		double E = 0;
+		for (int n = 0; n < code.CodeLen; n++) E += code.VarDegree[n];
+		const double w = 8.0 * (code.GFq - 1), N = code.CodeLen, D = (sim.decodeMethod == 2) ? 0 : 1;
+		sim.bytes_per_frame = w * N + 4 * N + 4;
+		sim.bytes_per_iter = w * (N + 4 * E + D * E);
+	}
 	out_batch.assign((size_t)code.CodeLen * sim.parallel, 0);
 	iters.assign(sim.parallel, 0);
 	conv.assign(sim.parallel, 0);
@@ -177,6 +184,7 @@ void CLink::CountErrors(int slot)
 	for (int i = 0; i < P; i++) CComm::ErrAccumulate(sim, es[i], eb[i], ok[i]);
 	lanes[P - 1]->ErrRates(sim);
 	sim.decoded_frames += P;
+	for (int i = 0; i < P; i++) sim.decoded_iters += iters[i];
 	n_frames += P;
 }
 

@@ -65,6 +65,7 @@ int CSimulation::ClearSimuCount()
 	errFrame = errBit = errSym = 0;
 	U_errFrame = U_errBit = U_errSym = 0;
 	decoded_frames = 0;
+	decoded_iters = 0;
 	start = clock();
 	wall_start = wall_now();
 	return 0;
@@ -123,7 +124,11 @@ int CSimulation::Show(int mode)
 		     << 1.0 * (stop - start) / CLOCKS_PER_SEC << endl;
 		const double wall = wall_now() - wall_start;
 		cout << std::defaultfloat << "      frames " << decoded_frames << "  wall " << wall << " s  " << (wall > 0 ? decoded_frames / wall : 0.0)
-		     << " codewords/s (link chain + decode)" << endl;
+		     << " codewords/s (link chain + decode)";
+		if (wall > 0 && bytes_per_iter > 0)
+			cout << "  " << (decoded_frames * bytes_per_frame + decoded_iters * bytes_per_iter) / wall * 1e-9 << " algorithmic GB/s ("
+			     << (decoded_frames > 0 ? decoded_iters / decoded_frames : 0.0) << " iterations per frame)";
+		cout << endl;
 		break;
 	}
 	default: break;

@@ -35,6 +35,8 @@ public:
 	clock_t start = 0, stop = 0;
 	double wall_start = 0;       // extension: wall-clock seconds (the reference reports CPU time only)
 	double decoded_frames = 0;   // extension: frames decoded at this Eb/N0 point
+	double decoded_iters = 0;    // extension: iterations those frames ran (early exit: up to the first zero syndrome)
+	double bytes_per_frame = 0, bytes_per_iter = 0; // extension: algorithmic bytes: 8(q-1)[N + I (N + 4E + D E)] per frame
 
 	int Initial(const std::string &profilename);
 	int Show(int mode);
