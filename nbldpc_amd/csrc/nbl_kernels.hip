@@ -163,6 +163,65 @@ __global__ __launch_bounds__(256) void vn_kernel(NblGraphDev g, NblWork w, NblRu
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The same variable-node pass for small fields (q <= 32): 64 / q variables per wave, lane = (variable of the wave, symbol).
+// One variable per wave leaves 48 of 64 lanes idle at q = 16 and makes the launch a million tiny waves; the arithmetic per
+// variable is unchanged (same sums in the same order, same decision rule), only the reductions run inside groups of q lanes.
+// ---------------------------------------------------------------------------------------------------------
+template <int Q> __device__ __forceinline__ double group_max(double v)
+{
+#pragma unroll
+	for (int mk = 1; mk < Q; mk <<= 1) v = dmax(v, __shfl_xor(v, mk, 64));
+	return v;
+}
+// DecideLLRVector (:1542-1562) inside a group of Q lanes: lowest symbol among the maxima of {0, v}; v of symbol 0 must be <= 0
+template <int Q> __device__ __forceinline__ int group_decide(double v, int sub)
+{
+	const double mx = dmax(group_max<Q>(v), 0.0);
+	const uint64_t hit = __ballot(v == mx);
+	const unsigned grp = (unsigned)((hit >> (sub * Q)) & ((Q == 32) ? 0xffffffffull : ((1ull << Q) - 1)));
+	return (mx > 0.0 && grp) ? __builtin_ctz(grp) : 0;
+}
+
+template <int Q, bool DAMP>
+__global__ __launch_bounds__(256) void vn_packed_kernel(NblGraphDev g, NblWork w, NblRun r)
+{
+	constexpr int G = 64 / Q;
+	const int lane = lane_id(), sub = lane / Q, a = lane % Q;
+	const long long node = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + sub;
+	int b = -1, n = 0;
+	if (node < (long long)r.B * g.N) {
+		b = nbl_codeword(w, r, (int)(node / g.N));
+		n = (int)(node % g.N);
+		if (b >= 0 && !r.fixed_iters && w.done[b]) b = -1;
+	}
+	const bool live = b >= 0;
+	const int bb = live ? b : 0; // idle groups compute on codeword 0 / variable 0 and store nothing
+	const int e0 = g.voff[live ? n : 0], dv = live ? g.voff[n + 1] - e0 : 0;
+	const double *L = w.Lch + ((size_t)bb * g.N + (live ? n : 0)) * Q;
+	const double *C = w.c2v + (size_t)bb * g.E * Q;
+	double *V = w.v2c + ((size_t)bb * g.E + e0) * Q;
+
+	double post = L[a];
+	for (int d = 0; d < g.maxdv; d++)
+		if (d < dv) post = post + C[(size_t)g.v_cpos[e0 + d] * Q + a];
+	const int dec = group_decide<Q>(post, sub);
+	if (live && a == 0) w.dec[(size_t)b * g.N + n] = dec;
+	if (live && w.post) w.post[((size_t)b * g.N + n) * Q + a] = post;
+	for (int d = 0; d < g.maxdv; d++) {
+		const bool on = d < dv; // (the group reductions below need every lane of the wave, so the loop bound is the wave's)
+		const size_t co = on ? (size_t)g.v_cpos[e0 + d] * Q + a : (size_t)a;
+		double nv = post - C[co];
+		if (DAMP) {
+			const double ov = on ? V[(size_t)d * Q + a] : 0.0;
+			const int before = group_decide<Q>(ov, sub), after = group_decide<Q>(nv, sub);
+			const double blend = __dadd_rn(__dmul_rn(r.damp_old, ov), __dmul_rn(r.damp_new, nv));
+			nv = (before != after) ? blend : nv;
+		}
+		if (on) V[(size_t)d * Q + a] = (a == 0) ? 0.0 : nv;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // syndrome + output freeze: one wave per codeword, lanes over checks (NBLDPC.cpp:693-715 / 826-846 / 999-1026)
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void syn_kernel(NblGraphDev g, NblWork w, NblRun r)
@@ -567,7 +626,22 @@ hipError_t nbl_launch_demod(const double *d_rx, int L, double sigma, int mod_ord
 hipError_t nbl_launch_vn(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool damp, hipStream_t st)
 {
 	long long nodes = (long long)r.B * g.N;
-	dim3 grid((unsigned)((nodes + 3) / 4)), block(256);
+	dim3 block(256);
+	if (g.q <= 32 && !getenv("NBL_VN_UNPACKED")) { // small fields: 64 / q variables per wave
+		const long long waves = (nodes + (64 / g.q) - 1) / (64 / g.q);
+		dim3 pgrid((unsigned)((waves + 3) / 4));
+#define NBL_VNP(QQ) { if (damp) vn_packed_kernel<QQ, true><<<pgrid, block, 0, st>>>(g, w, r); else vn_packed_kernel<QQ, false><<<pgrid, block, 0, st>>>(g, w, r); }
+		switch (g.q) {
+		case 4: NBL_VNP(4) break;
+		case 8: NBL_VNP(8) break;
+		case 16: NBL_VNP(16) break;
+		case 32: NBL_VNP(32) break;
+		default: return hipErrorInvalidValue;
+		}
+#undef NBL_VNP
+		return hipGetLastError();
+	}
+	dim3 grid((unsigned)((nodes + 3) / 4));
 	if (damp) { NBL_DISPATCH_Q(g.q, vn_kernel<QQ, true><<<grid, block, 0, st>>>(g, w, r)) }
 	else { NBL_DISPATCH_Q(g.q, vn_kernel<QQ, false><<<grid, block, 0, st>>>(g, w, r)) }
 	return hipGetLastError();
