@@ -33,6 +33,11 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 U128_16 = "divsalar.UNBLDPC.128.64.GF.16"
 U128_256 = "divsalar.UNBLDPC.128.64.GF.256"
 U512_256 = "divsalar.UNBLDPC.512.256.GF.256"
+U256_16 = "divsalar.UNBLDPC.256.128.GF.16"
+U512_16 = "divsalar.UNBLDPC.512.256.GF.16"
+U256_256 = "divsalar.UNBLDPC.256.128.GF.256"
+C256_256 = "divsalar.CNBLDPC.256.128.GF.256"
+C128_256 = "divsalar.CNBLDPC.128.64.GF.256"
 C512_256 = "divsalar.CNBLDPC.512.256.GF.256"
 BDS = "BDS.576.288.GF.64"
 
@@ -62,6 +67,19 @@ SETS = {
     "tems_gf16_dc5": ("O2", dict(gfq=16, code=U128_16, method=4, max_iter=20, parallel=4, tems_nr=2, tems_nc=2,
                                  tems_factor=1.1, tems_offset=0.05, constellation="BPSK"), 2.0, 4, [1, 2, 5, 20],
                       [1, 2, 3], [0, 1, 2, 3]),
+    # the other shipped codes: mixed check degrees 4 / 5 (GF(16) 256.128 and 512.256), T-EMS over GF(256), the CNBLDPC family
+    "ems_gf16_u256_mixed": ("O2", dict(gfq=16, code=U256_16, method=2, max_iter=20, parallel=4, ems_nm=8, ems_nc=3,
+                                       constellation="BPSK"), 2.0, 4, [1, 2, 5, 20], [1, 2], [0, 1]),
+    "tems_gf16_u512_mixed": ("O2", dict(gfq=16, code=U512_16, method=4, max_iter=20, parallel=4, tems_nr=2, tems_nc=3,
+                                        constellation="BPSK"), 2.0, 4, [1, 2, 5, 20], [1, 2], [0, 1]),
+    "bp_gf16_u256_mixed": ("O0", dict(gfq=16, code=U256_16, method=1, max_iter=20, parallel=4, constellation="BPSK"),
+                           2.0, 4, [1, 2, 5, 20], [1, 2], [0, 1]),
+    "tems_gf256_u256": ("O2", dict(gfq=256, code=U256_256, method=4, max_iter=20, parallel=3, tems_nr=2, tems_nc=3,
+                                   constellation="BPSK"), 1.5, 3, [1, 2, 5, 20], [1, 2], [0]),
+    "ems_c256_qam": ("O2", dict(gfq=256, code=C256_256, method=2, max_iter=30, parallel=3, ems_nm=16, ems_nc=2, nqam=256,
+                                constellation="GRAY_256QAM", random_msg=0), 3.5, 3, [1, 2, 5, 30], [1, 2], [0]),
+    "tems_c128_nr3": ("O2", dict(gfq=256, code=C128_256, method=4, max_iter=20, parallel=3, tems_nr=3, tems_nc=2, tems_factor=1.05,
+                                 tems_offset=0.02, constellation="BPSK"), 2.0, 3, [1, 2, 5, 20], [1, 2], [0]),
     # cfg 5: BP / log-QSPA, GF(256), 256-QAM, all-zero codeword; 2.2 s per iteration per codeword on the CPU
     "cfg5_bp_c512": ("O0", dict(gfq=256, code=C512_256, method=1, max_iter=100, parallel=1, nqam=256,
                                 constellation="GRAY_256QAM", random_msg=0), 10.0, 2, [1, 2, 3], [1, 2], [0]),

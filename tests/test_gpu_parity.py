@@ -17,8 +17,10 @@ import nbldpc_amd.datafiles as df
 
 pytestmark = pytest.mark.gpu
 
-EMS_SETS = ["cfg2_ems_u128", "cfg3_ems_u512", "ems_nc2_shaped", "ems_nc1", "ems_gf16_dc5", "ems_gf16_nc4"]
-TEMS_SETS = ["cfg4_tems_bds", "tems_gf16_dc5"]
+EMS_SETS = ["cfg2_ems_u128", "cfg3_ems_u512", "ems_nc2_shaped", "ems_nc1", "ems_gf16_dc5", "ems_gf16_nc4",
+            "ems_gf16_u256_mixed", "ems_c256_qam"]
+TEMS_SETS = ["cfg4_tems_bds", "tems_gf16_dc5", "tems_gf16_u512_mixed", "tems_gf256_u256", "tems_c128_nr3"]
+IRREGULAR = ("tems_gf16_dc5", "tems_gf16_u512_mixed", "ems_gf16_u256_mixed")  # check degrees 4 and 5 mixed
 LLR_TOL = 1e-9
 
 
@@ -37,8 +39,8 @@ def _oracle_decoder(oracle, meta, max_iter, fixed=0):
 @pytest.mark.parametrize("generic", [0, 1, 2])
 @pytest.mark.parametrize("name", EMS_SETS + TEMS_SETS)
 def test_decisions_equal_reference(name, generic):
-    if generic == 2 and name == "tems_gf16_dc5":
-        pytest.skip("irregular GF(16) code: no specialised T-EMS kernel, variants 1 and 2 are the same launch sequence")
+    if generic == 2 and name in IRREGULAR:
+        pytest.skip("irregular GF(16) code: no specialised kernel, variants 1 and 2 are the same launch sequence")
     g, meta = load_golden(name)
     p, kw = meta["profile"], decoder_kwargs(meta["profile"])
     code = nb.Code(meta["code"])
@@ -55,8 +57,8 @@ def test_decisions_equal_reference(name, generic):
 @pytest.mark.parametrize("generic", [0, 1, 2])
 @pytest.mark.parametrize("name", EMS_SETS + TEMS_SETS)
 def test_state_bit_exact_vs_oracle_and_close_to_reference(oracle, name, generic):
-    if generic == 2 and name == "tems_gf16_dc5":
-        pytest.skip("irregular GF(16) code: no specialised T-EMS kernel, variants 1 and 2 are the same launch sequence")
+    if generic == 2 and name in IRREGULAR:
+        pytest.skip("irregular GF(16) code: no specialised kernel, variants 1 and 2 are the same launch sequence")
     g, meta = load_golden(name)
     p, kw = meta["profile"], decoder_kwargs(meta["profile"])
     code = nb.Code(meta["code"])
@@ -77,7 +79,7 @@ def test_state_bit_exact_vs_oracle_and_close_to_reference(oracle, name, generic)
         dec.close()
 
 
-@pytest.mark.parametrize("name", ["cfg1_bp_gf16", "cfg5_bp_c512"])
+@pytest.mark.parametrize("name", ["cfg1_bp_gf16", "cfg5_bp_c512", "bp_gf16_u256_mixed"])
 def test_bp_decisions_equal_reference_and_llrs_close(oracle, name):
     """log-QSPA: the reference accumulates in 80-bit long double with glibc expl/logl, which no GPU can reproduce bit for
     bit (SURVEY 8c hazard 3).  Parity = identical hard decisions and zero-syndrome flags on the reference's recorded frames,
