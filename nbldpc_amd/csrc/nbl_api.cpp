@@ -31,6 +31,7 @@ struct nbl_decoder {
 	hipStream_t stream = nullptr;
 	bool record_state = false;
 	bool all_dc4 = false;       // every check has degree 4
+	int min_dc = 0;             // smallest check degree
 	bool all_dv2 = false;       // every variable has degree 2
 	double *c2v_alt = nullptr;  // second c2v buffer of the fused EMS iteration (flooding schedule -> double buffer)
 	double *c2v_zero = nullptr; // fused iterations: the all-zero c2v of iteration 0, written once when the workspace is made and only
@@ -291,6 +292,8 @@ extern "C" nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_m
 	d->d_e2c_map = (int *)d->g.v_cpos;
 	d->all_dc4 = true;
 	for (int m = 0; m < M; m++) d->all_dc4 = d->all_dc4 && (code->chk_deg[m] == 4);
+	d->min_dc = code->chk_deg[0];
+	for (int m = 0; m < M; m++) d->min_dc = code->chk_deg[m] < d->min_dc ? code->chk_deg[m] : d->min_dc;
 	d->all_dv2 = true;
 	for (int n = 0; n < N; n++) d->all_dv2 = d->all_dv2 && (code->var_deg[n] == 2);
 	if (q == 256 && d->all_dc4) {
@@ -406,18 +409,22 @@ extern "C" nbl_status nbl_last_timing(nbl_decoder *d, double ms[4], int64_t laun
 
 static nbl_status launch_cn(nbl_decoder *d, const NblRun &r, hipStream_t st)
 {
+	static const bool small_on = !getenv("NBL_NO_SMALL"); // A/B measurements: the one-check-per-wave kernels on small fields
 	switch (d->prm.method) {
 	case NBL_METHOD_EMS:
 		if (d->force_generic != 1 && nbl_ems256_applicable(d->g, d->all_dc4, r.nm, r.nc)) HIP_TRY(d, nbl_launch_cn_ems256(d->g, d->w, r, false, st));
+		else if (d->force_generic != 1 && small_on && nbl_small_applicable(d->g, NBL_METHOD_EMS, d->min_dc, r.nm, r.nc)) HIP_TRY(d, nbl_launch_cn_ems_small(d->g, d->w, r, st));
 		else HIP_TRY(d, nbl_launch_cn_ems(d->g, d->w, r, st));
 		break;
 	case NBL_METHOD_TEMS:
 		if (d->force_generic != 1 && nbl_tems64_applicable(d->g, d->all_dc4, r.nr, r.nc)) HIP_TRY(d, nbl_launch_cn_tems64(d->g, d->w, r, false, st));
 		else if (d->force_generic != 1 && nbl_tems256_applicable(d->g, d->all_dc4, r.nr, r.nc)) HIP_TRY(d, nbl_launch_cn_tems256(d->g, d->w, r, false, st));
+		else if (d->force_generic != 1 && small_on && nbl_small_applicable(d->g, NBL_METHOD_TEMS, d->min_dc, 0, r.nc)) HIP_TRY(d, nbl_launch_cn_tems_small(d->g, d->w, r, st));
 		else HIP_TRY(d, nbl_launch_cn_tems(d->g, d->w, r, st));
 		break;
 	case NBL_METHOD_BP:
 		if (d->force_generic != 1 && nbl_bp256_applicable(d->g, d->all_dc4)) HIP_TRY(d, nbl_launch_cn_bp256(d->g, d->w, r, false, st));
+		else if (d->force_generic != 1 && small_on && nbl_small_applicable(d->g, NBL_METHOD_BP, d->min_dc, 0, 0)) HIP_TRY(d, nbl_launch_cn_bp_small(d->g, d->w, r, st));
 		else HIP_TRY(d, nbl_launch_cn_bp(d->g, d->w, r, st));
 		break;
 	default: d->err = "check-node kernel for this method is not built yet"; return NBL_ERR_UNSUPPORTED;

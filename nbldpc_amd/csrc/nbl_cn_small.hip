@@ -1,0 +1,599 @@
+// nbldpc_amd/csrc/nbl_cn_small.hip -- check-node kernels for small fields (q <= 32: the three shipped GF(16) codes, BASELINE
+// config 1): EMS (NBLDPC.cpp:859-917), T-EMS (:1055-1130) and log-QSPA (:747-767).
+//
+// The general kernels (nbl_kernels.hip, nbl_cn_tems.hip, nbl_cn_bp.hip) give every check a whole wave, lane = symbol: at q = 16
+// three quarters of the lanes idle and every step of the (short, latency-bound) chain of LDS phases is paid per check.  Here a
+// wave holds 64 / q checks: lane = (check of the wave, symbol), every group of q lanes works on its own LDS region, reductions
+// run inside the group (DPP row operations: a group never spans a DPP row boundary it does not own).  The arithmetic per check
+// is the general kernels' -- the same candidates, the same left-to-right sums, the same tie rules -- so the results are
+// bit-identical to theirs for EMS and T-EMS (tests/test_gpu_parity.py runs both and the oracle); log-QSPA keeps vectors as
+// mantissa x 2^exponent like nbl_cn_bp256.hip (LLRs within 1e-9 of the oracle's FP64 restatement, identical decisions).
+//
+// Groups of one wave are independent: checks of different degree (the GF(16) codes mix 4 and 5), different candidate counts or
+// different numeric ranges simply diverge; no lane of one group ever reads a register of another.  One wave per workgroup, so
+// the phases only need the compiler to keep the order of the LDS operations (WSYNC), not a barrier.
+#include <hip/hip_runtime.h>
+#include "nbl_device.h"
+#include "nbl_fastmath.h"
+#include "nbl_kernels.h"
+
+namespace {
+
+#define WSYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+
+template <int CTRL> __device__ __forceinline__ double dppx_f64(double x)
+{
+	const int lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), CTRL, 0xF, 0xF, false);
+	const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), CTRL, 0xF, 0xF, false);
+	return __hiloint2double(hi, lo);
+}
+// maximum over the Q lanes of the group, delivered to every lane of it (butterfly: xor 1, xor 2, mirror 8, mirror 16, xor 16)
+template <int Q> __device__ __forceinline__ double gmax_f64(double v)
+{
+	if (Q >= 2) v = dmax(v, dppx_f64<0xB1>(v));   // quad_perm [1,0,3,2]
+	if (Q >= 4) v = dmax(v, dppx_f64<0x4E>(v));   // quad_perm [2,3,0,1]
+	if (Q >= 8) v = dmax(v, dppx_f64<0x141>(v));  // row_half_mirror
+	if (Q >= 16) v = dmax(v, dppx_f64<0x140>(v)); // row_mirror
+	if (Q >= 32) v = dmax(v, __shfl_xor(v, 16, 64));
+	return v;
+}
+template <int Q> __device__ __forceinline__ int gmax_i32(int v)
+{
+	constexpr int ID = (int)0x80000000;
+	if (Q >= 2) v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0xB1, 0xF, 0xF, false));
+	if (Q >= 4) v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0x4E, 0xF, 0xF, false));
+	if (Q >= 8) v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0x141, 0xF, 0xF, false));
+	if (Q >= 16) v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0x140, 0xF, 0xF, false));
+	if (Q >= 32) v = max(v, __shfl_xor(v, 16, 64));
+	return v;
+}
+// the group's bits of a wave ballot, bit i = lane i of the group
+template <int Q> __device__ __forceinline__ unsigned gballot(bool p, int gi)
+{
+	const uint64_t m = __ballot(p);
+	return (unsigned)(m >> (gi * Q)) & ((Q == 32) ? 0xffffffffu : ((1u << (Q & 31)) - 1u));
+}
+
+// which (codeword, check) the lane's group works on
+template <int Q> struct Ctx { int gi, sl, b, c0, dc; bool live; };
+template <int Q> __device__ __forceinline__ Ctx<Q> ctx_init(const NblGraphDev &g, const NblWork &w, const NblRun &r)
+{
+	constexpr int P = Fld<Q>::P, G = 64 / Q;
+	Ctx<Q> c;
+	const int lane = lane_id();
+	c.gi = lane >> P;
+	c.sl = lane & (Q - 1);
+	const long long ci = (long long)blockIdx.x * G + c.gi, total = (long long)r.B * g.M;
+	c.b = -1;
+	int m = 0;
+	if (ci < total) {
+		c.b = nbl_codeword(w, r, (int)(ci / g.M));
+		m = (int)(ci % g.M);
+		if (c.b >= 0 && !r.fixed_iters && w.done[c.b]) c.b = -1;
+	}
+	c.live = c.b >= 0;
+	c.c0 = c.live ? g.coff[m] : 0;
+	c.dc = c.live ? g.coff[m + 1] - c.c0 : 0;
+	return c;
+}
+
+// =====================================================================================================================
+// T-EMS (the steps and their reference lines are those of cn_tems_fast_kernel, nbl_cn_tems.hip; nc <= 3)
+// =====================================================================================================================
+struct __attribute__((aligned(16))) TState { double v[4]; unsigned c[4]; };
+struct __attribute__((aligned(16))) TCand { double u; int q; int pad; };
+
+__host__ __device__ inline size_t tems_small_group_bytes(int q, int mdc)
+{
+	const size_t n = (size_t)8 * (mdc * q + q) + (size_t)2 * q * sizeof(TState) + (size_t)mdc * (q + 4) * sizeof(TCand) + (size_t)4 * (2 * q + 2 * mdc);
+	return (n + 15) & ~(size_t)15;
+}
+
+template <int Q>
+__global__ __launch_bounds__(64) void cn_tems_small_kernel(NblGraphDev g, NblWork w, NblRun r)
+{
+	constexpr int P = Fld<Q>::P;
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const Ctx<Q> c = ctx_init<Q>(g, w, r);
+	if (!c.live) return;
+	const int sl = c.sl, dc = c.dc, c0 = c.c0, nr = r.nr, nc = r.nc, mdc = g.maxdc;
+	char *base = smem + (size_t)c.gi * tems_small_group_bytes(Q, mdc);
+	double *dU = (double *)base;                 // [mdc][Q]
+	double *Lc = dU + mdc * Q;                   // [Q]
+	TState *st = (TState *)(Lc + Q);             // [2][Q] DP states (ping-pong)
+	TCand *cl = (TCand *)(st + 2 * Q);           // [mdc][Q+4] deviation candidates per column
+	int *ord01 = (int *)(cl + mdc * (Q + 4));    // [Q] first two columns of the per-symbol order
+	int *cmask = ord01 + Q;                      // [Q] bit d set: column d may deviate to this symbol
+	int *ccount = cmask + Q;                     // [mdc]
+	int *beta = ccount + mdc;                    // [mdc]
+
+	const double *V = w.v2c + (size_t)c.b * g.E * Q;
+	double *C = w.c2v + ((size_t)c.b * g.E + c0) * Q;
+
+	// ---- 1. beta, syndrome, dU (TEMS_Get_Beta :1789-1812, TEMS_Get_deltaU :1814-1834) -------------------------------
+	int syn = 0;
+	for (int d = 0; d < dc; d++) {
+		const double *Vd = V + (size_t)g.c_epos[c0 + d] * Q;
+		const double v = (sl > 0) ? Vd[sl] : 0.0;
+		// most reliable symbol: strict '>' over ascending symbols from a running maximum of 0 (:1798-1807)
+		const double mx = dmax(gmax_f64<Q>(v), 0.0);
+		const unsigned hit = gballot<Q>(v == mx, c.gi);
+		const int arg = (mx > 0.0 && hit) ? __builtin_ctz(hit) : 0;
+		const uint8_t *mrow = g.mul + (size_t)g.c_h[c0 + d] * Q;
+		const int bd = mrow[arg]; // beta_d = h * argmax (0 if nothing positive)
+		if (sl == 0) beta[d] = bd;
+		syn ^= bd;
+		dU[d * Q + (mrow[sl] ^ bd)] = mx - v; // dU[d][h a ^ beta] = mx - L(a), L(0) = 0  (:1826-1831)
+	}
+	for (int d = sl; d < dc; d += Q) ccount[d] = 0;
+	WSYNC();
+
+	// ---- 2. per deviation symbol: stable ascending order of the columns, Nr smallest marked (TEMS_Get_Min :1836-1890) ----
+	{
+		int mask = 0, o0 = 0, o1 = 0;
+		for (int d = 0; d < dc; d++) {
+			const double ud = dU[d * Q + sl];
+			int rank = 0;
+			for (int e = 0; e < dc; e++) {
+				const double ue = dU[e * Q + sl];
+				rank += (ue < ud || (ue == ud && e < d)) ? 1 : 0;
+			}
+			if (rank < nr) mask |= 1 << d;
+			if (rank == 0) o0 = d;
+			if (rank == 1) o1 = d;
+		}
+		if (sl == 0) mask = (1 << dc) - 1;
+		cmask[sl] = mask;
+		ord01[sl] = o0 | (o1 << 8);
+		// candidate lists per column (non-zero symbols only; symbol 0 = "no deviation" is handled apart), packed {dU, symbol}
+		if (sl > 0) {
+			for (int d = 0; d < dc; d++)
+				if ((mask >> d) & 1) {
+					TCand e;
+					e.u = dU[d * Q + sl];
+					e.q = sl;
+					e.pad = 0;
+					cl[d * (Q + 4) + atomicAdd(&ccount[d], 1)] = e;
+				}
+		}
+	}
+	WSYNC();
+	if (sl < 4) { // pad every list to a multiple of four with entries that can never win (cost +inf)
+		for (int d = 0; d < dc; d++) {
+			const int n = ccount[d];
+			if (n + sl < ((n + 3) & ~3)) {
+				TCand e;
+				e.u = __builtin_huge_val();
+				e.q = 0;
+				e.pad = 0;
+				cl[d * (Q + 4) + n + sl] = e;
+			}
+		}
+	}
+
+	// ---- 3. min-plus DP over the columns; all deviation-count layers advance together (TEMS_ConstructConf :1892-1944) ----
+	TState *A = st, *Bs = st + Q;
+	{
+		TState z;
+#pragma unroll
+		for (int l = 0; l < 4; l++) { z.v[l] = __builtin_huge_val(); z.c[l] = 0; }
+		if (sl == 0) z.v[0] = 0.0;
+		A[sl] = z;
+	}
+	WSYNC();
+	for (int d = 0; d < dc; d++) {
+		const int n4 = (ccount[d] + 3) & ~3;
+		const TCand *L = cl + d * (Q + 4);
+		TState b = A[sl]; // q_d = 0: dU[d][0] = 0 (:1826), cost unchanged
+#pragma unroll
+		for (int l = 0; l < 4; l++) { b.v[l] = b.v[l] + 0.0; b.c[l] = b.c[l] * Q; }
+		for (int k = 0; k < n4; k += 4) {
+			TCand e[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) e[u] = L[k + u];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const TState src = A[sl ^ e[u].q];
+#pragma unroll
+				for (int l = 1; l < 4; l++) {
+					if (l <= nc && l <= d + 1) { // a path through d+1 columns has at most d+1 deviations
+						const double val = src.v[l - 1] + e[u].u;
+						const unsigned code = src.c[l - 1] * Q + e[u].q;
+						// smaller cost wins, equal cost: smaller path code
+						const bool lt = val < b.v[l];
+						b.v[l] = lt ? val : b.v[l];
+						b.c[l] = lt ? code : b.c[l];
+						const unsigned cm = code < b.c[l] ? code : b.c[l];
+						b.c[l] = (val == b.v[l]) ? cm : b.c[l];
+					}
+				}
+			}
+		}
+		Bs[sl] = b;
+		WSYNC();
+		TState *tsw = A; A = Bs; Bs = tsw;
+	}
+	// dW, Eta: best layer per check sum
+	double dW = __builtin_huge_val();
+	unsigned eta = 0xffffffffu;
+	{
+		const TState f = A[sl];
+#pragma unroll
+		for (int l = 0; l < 4; l++)
+			if (l <= nc && (f.v[l] < dW || (f.v[l] == dW && f.c[l] < eta))) { dW = f.v[l]; eta = f.c[l]; }
+	}
+
+	// ---- 4. outputs (:1075-1129) -----------------------------------------------------------------------------------------
+	int pshift = (dc - 1) * P; // digit of column d sits at bit P*(dc-1-d) of the path code
+	for (int d = 0; d < dc; d++) {
+		WSYNC();
+		Lc[sl] = NBL_DBL_MAX;
+		WSYNC();
+		{
+			const int dev = (int)((eta >> pshift) & (Q - 1));
+			const double cand = dW - dU[d * Q + dev];                            // :1088
+			__hip_atomic_fetch_min(&Lc[sl ^ dev], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		WSYNC();
+		if (Lc[sl] == NBL_DBL_MAX) {                                             // never reached (:1095-1102)
+			const int o0 = ord01[sl] & 255, o1 = (ord01[sl] >> 8) & 255;
+			Lc[sl] = (d == o0) ? dU[o1 * Q + sl] : dU[o0 * Q + sl];
+		}
+		WSYNC();
+		// delta domain -> LLR, un-permute by h (:1105-1127)
+		const int bsyn = syn ^ beta[d];
+		const double L0 = -1.0 * Lc[bsyn];
+		const uint8_t *mrow = g.mul + (size_t)g.c_h[c0 + d] * Q;
+		const int e = mrow[sl] ^ bsyn; // eta with h^-1 (eta ^ bsyn) = a
+		C[(size_t)d * Q + sl] = (sl == 0) ? 0.0 : shape_llr(-1.0 * Lc[e] - L0, r.factor, r.offset);
+		pshift -= P;
+	}
+}
+
+// =====================================================================================================================
+// EMS (max-plus dynamic programme of cn_ems_kernel, nbl_kernels.hip)
+// =====================================================================================================================
+__host__ __device__ inline size_t ems_small_group_bytes(int q, int mdc, int nm, int layers)
+{
+	const size_t n = (size_t)8 * ((size_t)mdc * q + (2 * (size_t)layers + 1) * q + (size_t)mdc * nm) + (size_t)4 * mdc * nm;
+	return (n + 15) & ~(size_t)15;
+}
+
+template <int Q>
+__global__ __launch_bounds__(64) void cn_ems_small_kernel(NblGraphDev g, NblWork w, NblRun r, int layers)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const Ctx<Q> c = ctx_init<Q>(g, w, r);
+	if (!c.live) return;
+	const int sl = c.sl, dc = c.dc, c0 = c.c0, nm = r.nm, mdc = g.maxdc;
+	char *base = smem + (size_t)c.gi * ems_small_group_bytes(Q, mdc, nm, layers);
+	double *U = (double *)base;        // [mdc][Q]   check-domain input vectors: U[j][h_j*a] = v2c_j[a], U[j][0] = 0
+	double *A0 = U + mdc * Q;          // [layers][Q] DP ping
+	double *B0 = A0 + layers * Q;      // [layers][Q] DP pong
+	double *Sv = B0 + layers * Q;      // [Q]        variable-domain copy for the ranking, then the maxima of the current output edge
+	double *lv = Sv + Q;               // [mdc][nm]  values of the nm most reliable entries, by rank (rank 0 first)
+	int *lt = (int *)(lv + mdc * nm);  // [mdc][nm]  their check-domain symbols
+
+	const double *V = w.v2c + (size_t)c.b * g.E * Q;
+	double *C = w.c2v + ((size_t)c.b * g.E + c0) * Q;
+
+	// ---- stage the dc incoming vectors: permute into the check domain, rank, keep the nm best ---------------------------
+	for (int j = 0; j < dc; j++) {
+		const double *Vj = V + (size_t)g.c_epos[c0 + j] * Q;
+		const double v = (sl > 0) ? Vj[sl] : 0.0;
+		const int t = g.mul[(size_t)g.c_h[c0 + j] * Q + sl];
+		U[j * Q + t] = v;
+		WSYNC();
+		Sv[sl] = v;
+		WSYNC();
+		// rank under SortLLRVector's order (:1715-1746): value descending, among equal values the HIGHER symbol first
+		int rank = 0;
+#pragma unroll 4
+		for (int x = 0; x < Q; x++) {
+			const double vo = Sv[x];
+			rank += (vo > v || (vo == v && x > sl)) ? 1 : 0;
+		}
+		if (rank < nm) { lv[j * nm + rank] = v; lt[j * nm + rank] = t; }
+	}
+	WSYNC();
+
+	// ---- one output edge at a time -----------------------------------------------------------------------------------------
+	for (int x = 0; x < dc; x++) {
+#define OTH(l) ((l) + ((l) >= x ? 1 : 0))
+		const int rn = dc - 1;
+		int zall = 0;
+		for (int l = 0; l < rn; l++) zall ^= lt[OTH(l) * nm];
+		double S = -NBL_DBL_MAX;
+
+		// conf(q,1): at most one edge deviates, to ANY symbol (:894)
+		for (int pi = 0; pi < rn; pi++) {
+			const int jd = OTH(pi);
+			const int shift = zall ^ lt[jd * nm];
+			const double u = U[jd * Q + (sl ^ shift)];
+			double acc = 0.0;
+			for (int l = 0; l < rn; l++) acc = acc + ((l == pi) ? u : lv[OTH(l) * nm]);
+			S = dmax(S, acc);
+		}
+
+		// conf(nm,nc): at most nc edges deviate, each inside its nm best (:897)
+		double *A = A0, *Bq = B0;
+		WSYNC();
+		if (layers == 1) {
+			// nc >= dc-1: no deviation counting needed -> plain truncated max-plus convolution
+			A[sl] = NBL_NEG_INF;
+			WSYNC();
+			if (rn == 1) {
+				const int j1 = OTH(0);
+				for (int k = sl; k < nm; k += Q) A[lt[j1 * nm + k]] = 0.0 + lv[j1 * nm + k];
+			} else {
+				const int j1 = OTH(0), j2 = OTH(1);
+				for (int idx = sl; idx < nm * nm; idx += Q) {
+					const int k1 = idx / nm, k2 = idx - k1 * nm;
+					const double val = (0.0 + lv[j1 * nm + k1]) + lv[j2 * nm + k2];
+					__hip_atomic_fetch_max(&A[lt[j1 * nm + k1] ^ lt[j2 * nm + k2]], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			}
+			WSYNC();
+			for (int l = 2; l < rn; l++) {
+				const int jl = OTH(l);
+				double acc = NBL_NEG_INF;
+				for (int k = 0; k < nm; k++) acc = dmax(acc, A[sl ^ lt[jl * nm + k]] + lv[jl * nm + k]);
+				if (l == rn - 1) S = dmax(S, acc);
+				else {
+					Bq[sl] = acc;
+					WSYNC();
+					double *T = A; A = Bq; Bq = T;
+				}
+			}
+			if (rn <= 2) S = dmax(S, A[sl]);
+		} else {
+			// layered DP: A[d][s] = best value reaching check sum s with exactly d deviations
+			for (int d = 0; d < layers; d++) A[d * Q + sl] = (d == 0 && sl == 0) ? 0.0 : NBL_NEG_INF;
+			WSYNC();
+			for (int l = 0; l < rn; l++) {
+				const int jl = OTH(l);
+				const int z = lt[jl * nm];
+				const double mz = lv[jl * nm];
+				for (int d = 0; d < layers; d++) {
+					double acc = A[d * Q + (sl ^ z)] + mz;
+					// after l edges no path has more than l deviations: layer d-1 is still all -inf for d - 1 > l
+					if (d >= 1 && d <= l + 1)
+						for (int k = 1; k < nm; k++) acc = dmax(acc, A[(d - 1) * Q + (sl ^ lt[jl * nm + k])] + lv[jl * nm + k]);
+					Bq[d * Q + sl] = acc;
+				}
+				WSYNC();
+				double *T = A; A = Bq; Bq = T;
+			}
+			for (int d = 0; d < layers; d++) S = dmax(S, A[d * Q + sl]);
+		}
+
+		// ---- output: c2v[a] = shape(S[h_x a] - S[0]) (:899-916) ------------------------------------------------------------
+		WSYNC();
+		Sv[sl] = S;
+		WSYNC();
+		{
+			const double s0 = Sv[0];
+			const int t = g.mul[(size_t)g.c_h[c0 + x] * Q + sl];
+			C[(size_t)x * Q + sl] = (sl == 0) ? 0.0 : shape_llr(Sv[t] - s0, r.factor, r.offset);
+		}
+#undef OTH
+	}
+}
+
+// =====================================================================================================================
+// log-QSPA (check-domain XOR convolutions in the log-sum-exp semiring, forward / backward partials: nbl_cn_bp.hip;
+// vectors as probabilities relative to their maximum, mantissa x 2^exponent: nbl_cn_bp256.hip)
+// =====================================================================================================================
+constexpr double LOG2E = 1.4426950408889634, LN2 = 0.6931471805599453;
+
+struct SVec {    // the lane's symbol of a vector
+	double m;    // mantissa in [1,2]
+	int e;       // exponent, <= 0 up to the float rounding of the reference, clamped at -1e9
+	double mx;   // group-uniform: the (near-)maximum that was divided out (log domain)
+	double rng;  // group-uniform: upper bound of max - min (log domain)
+};
+
+template <int Q> __device__ __forceinline__ SVec to_svec(double L)
+{
+	SVec r;
+	// reference and range through order-preserving 32-bit keys (see to_xvec, nbl_cn_bp256.hip)
+	const int k = nbl_key32(L);
+	r.mx = (double)nbl_unkey32(gmax_i32<Q>(k));
+	const double mn = (double)nbl_unkey32(-gmax_i32<Q>(-k));
+	r.rng = (r.mx - mn) * (1.0 + 0x1p-20) + 0x1p-100;
+	const double y = dmax((L - r.mx) * LOG2E, -1.0e9);
+	const double f = floor(y);
+	r.m = nbl_exp2_frac(y - f);
+	r.e = (int)f;
+	return r;
+}
+
+struct BpLds {
+	double *Vm;  // [NV][Q] mantissas of the stored vectors
+	int *Ve;     // [NV][Q] exponents
+	double *Vx;  // [NV][2] {mx, rng}
+	double *Pa, *Pb; // [Q] operands of the running convolution (plain probabilities or mantissas)
+	int *Ea, *Eb;    // [Q] their exponents (wide path)
+	double *T;   // [Q] staging of an output vector
+};
+
+__host__ __device__ inline size_t bp_small_group_bytes(int q, int mdc)
+{
+	const int nv = 2 * mdc;
+	const size_t n = (size_t)nv * q * 12 + (size_t)nv * 16 + (size_t)q * 24 + (size_t)q * 8;
+	return (n + 15) & ~(size_t)15;
+}
+
+template <int Q> __device__ __forceinline__ void put_vec(const BpLds &s, int slot, const SVec &v, int sl)
+{
+	s.Vm[slot * Q + sl] = v.m;
+	s.Ve[slot * Q + sl] = v.e;
+	if (sl == 0) { s.Vx[2 * slot] = v.mx; s.Vx[2 * slot + 1] = v.rng; }
+}
+template <int Q> __device__ __forceinline__ SVec get_vec(const BpLds &s, int slot, int sl)
+{
+	SVec v;
+	v.m = s.Vm[slot * Q + sl];
+	v.e = s.Ve[slot * Q + sl];
+	v.mx = s.Vx[2 * slot];
+	v.rng = s.Vx[2 * slot + 1];
+	return v;
+}
+
+// out[z] = LSE_x(A[x] + B[z^x]) - LSE_x(A[x] + B[x]) for the lane's symbol z (log domain, out[0] = 0)
+template <int Q> __device__ __forceinline__ double lse_conv_small(const SVec &A, const SVec &B, const BpLds &s, int sl, int gi)
+{
+	constexpr int SH = 500; // see lse_conv, nbl_cn_bp256.hip
+	double lse;
+	WSYNC();
+	if (fmin(A.rng, B.rng) < 1000.0) { // (uniform inside the group)
+		s.Pa[sl] = ldexp(A.m, A.e + SH);
+		s.Pb[sl] = ldexp(B.m, B.e + SH);
+		WSYNC();
+		double acc = 0.0;
+#pragma unroll 4
+		for (int x = 0; x < Q; x++) acc = __fma_rn(s.Pa[x], s.Pb[sl ^ x], acc);
+		lse = ((nbl_log_pos(acc) - (2 * SH) * LN2) + A.mx) + B.mx;
+	} else {
+		s.Pa[sl] = A.m;
+		s.Pb[sl] = B.m;
+		s.Ea[sl] = A.e;
+		s.Eb[sl] = B.e;
+		WSYNC();
+		// exact top exponent of the output, then every term scaled exactly against it (far below the range gives 0)
+		int ex = INT_MIN;
+#pragma unroll 4
+		for (int x = 0; x < Q; x++) ex = max(ex, s.Ea[x] + s.Eb[sl ^ x]);
+		double acc = 0.0;
+#pragma unroll 4
+		for (int x = 0; x < Q; x++) {
+			const int d = s.Ea[x] + s.Eb[sl ^ x] - ex;
+			acc = __fma_rn(s.Pa[x], ldexp(s.Pb[sl ^ x], d), acc);
+		}
+		lse = ((nbl_log_pos(acc) + (double)ex * LN2) + A.mx) + B.mx;
+	}
+	const double norm = __shfl(lse, gi * Q, 64); // z = 0
+	return (sl == 0) ? 0.0 : lse - norm;
+}
+
+template <int Q>
+__global__ __launch_bounds__(64) void cn_bp_small_kernel(NblGraphDev g, NblWork w, NblRun r)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const Ctx<Q> c = ctx_init<Q>(g, w, r);
+	if (!c.live) return;
+	const int sl = c.sl, gi = c.gi, dc = c.dc, c0 = c.c0, mdc = g.maxdc, nv = 2 * mdc;
+	char *base = smem + (size_t)gi * bp_small_group_bytes(Q, mdc);
+	BpLds s;
+	s.Vm = (double *)base;
+	s.Vx = s.Vm + nv * Q;
+	s.Pa = s.Vx + 2 * nv;
+	s.Pb = s.Pa + Q;
+	s.T = s.Pb + Q;
+	s.Ve = (int *)(s.T + Q);
+	s.Ea = s.Ve + nv * Q;
+	s.Eb = s.Ea + Q;
+
+	const double *V = w.v2c + (size_t)c.b * g.E * Q;
+	double *C = w.c2v + ((size_t)c.b * g.E + c0) * Q;
+
+	// inputs into the check domain: p_d[h_d a] = v2c_d[a], symbol 0 = LLR 0 (the A1 == 0 branch of LLR_BoxPlus, :1623-1632);
+	// vector slots: p_d -> d, F_k (k = 2..dc-2) -> mdc + k - 2, the running R -> 2 mdc - 2 + (0 | 1)
+	for (int d = 0; d < dc; d++) {
+		const double *Vd = V + (size_t)g.c_epos[c0 + d] * Q;
+		const int t = g.mul[(size_t)g.c_h[c0 + d] * Q + sl];
+		WSYNC();
+		s.T[t] = (sl == 0) ? 0.0 : Vd[sl];
+		WSYNC();
+		put_vec<Q>(s, d, to_svec<Q>(s.T[sl]), sl);
+	}
+	WSYNC();
+
+	auto emit = [&](double o, int d) {
+		WSYNC();
+		s.T[sl] = o;
+		WSYNC();
+		const int t = g.mul[(size_t)g.c_h[c0 + d] * Q + sl];
+		C[(size_t)d * Q + sl] = (sl == 0) ? 0.0 : s.T[t];
+	};
+
+	// forward partials F_1 = p_0, F_k+1 = F_k [+] p_k; the last one, F_dc-1, is output dc-1 (A2 == 0 case, :761-764)
+	{
+		SVec F = get_vec<Q>(s, 0, sl);
+		for (int k = 1; k <= dc - 2; k++) {
+			const double o = lse_conv_small<Q>(F, get_vec<Q>(s, k, sl), s, sl, gi);
+			if (k + 1 == dc - 1) emit(o, dc - 1);
+			else {
+				F = to_svec<Q>(o);
+				put_vec<Q>(s, mdc + k - 1, F, sl); // F_k+1
+			}
+		}
+	}
+	// backward: R_dc-2 = p_dc-1; output d = F_d [+] R_d, R_d-1 = R_d [+] p_d; R_0 is output 0 (A1 == 0 case, :757-760)
+	{
+		SVec R = get_vec<Q>(s, dc - 1, sl);
+		for (int d = dc - 2; d >= 1; d--) {
+			WSYNC();
+			const SVec F = get_vec<Q>(s, (d == 1) ? 0 : mdc + d - 2, sl);
+			emit(lse_conv_small<Q>(F, R, s, sl, gi), d);
+			const double o = lse_conv_small<Q>(R, get_vec<Q>(s, d, sl), s, sl, gi);
+			if (d == 1) emit(o, 0);
+			else R = to_svec<Q>(o);
+		}
+	}
+}
+
+template <int Q> struct SmallLaunch {
+	static hipError_t tems(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
+	{
+		constexpr int G = 64 / Q;
+		const size_t lds = tems_small_group_bytes(Q, g.maxdc) * G;
+		const long long checks = (long long)r.B * g.M;
+		cn_tems_small_kernel<Q><<<dim3((unsigned)((checks + G - 1) / G)), dim3(64), lds, st>>>(g, w, r);
+		return hipGetLastError();
+	}
+	static hipError_t ems(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
+	{
+		constexpr int G = 64 / Q;
+		const int layers = nbl_ems_layers(g, r.nc);
+		const size_t lds = ems_small_group_bytes(Q, g.maxdc, r.nm, layers) * G;
+		const long long checks = (long long)r.B * g.M;
+		cn_ems_small_kernel<Q><<<dim3((unsigned)((checks + G - 1) / G)), dim3(64), lds, st>>>(g, w, r, layers);
+		return hipGetLastError();
+	}
+	static hipError_t bp(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
+	{
+		constexpr int G = 64 / Q;
+		const size_t lds = bp_small_group_bytes(Q, g.maxdc) * G;
+		const long long checks = (long long)r.B * g.M;
+		cn_bp_small_kernel<Q><<<dim3((unsigned)((checks + G - 1) / G)), dim3(64), lds, st>>>(g, w, r);
+		return hipGetLastError();
+	}
+};
+
+} // namespace
+
+// q <= 32, every check of degree >= 3 (the log-QSPA schedule below needs a middle edge), the LDS of a wave's 64 / q checks
+// within the 64 KB a launch gets without opting in; T-EMS: nc <= 3 and a path code of p * maxdc <= 32 bits as in the general kernel
+bool nbl_small_applicable(const NblGraphDev &g, int method, int min_dc, int nm, int nc)
+{
+	if (g.q > 32 || g.q < 4 || min_dc < 3 || g.maxdc > NBL_MAXDC) return false;
+	const int G = 64 / g.q;
+	if (method == 2) return ems_small_group_bytes(g.q, g.maxdc, nm, nbl_ems_layers(g, nc)) * G <= 64 * 1024;
+	if (method == 4) return nc <= 3 && g.p * g.maxdc <= 32 && tems_small_group_bytes(g.q, g.maxdc) * G <= 64 * 1024;
+	if (method == 1) return bp_small_group_bytes(g.q, g.maxdc) * G <= 64 * 1024;
+	return false;
+}
+
+#define NBL_DISPATCH_SMALL(q, CALL)                    \
+	switch (q) {                                       \
+	case 4: return SmallLaunch<4>::CALL(g, w, r, st);  \
+	case 8: return SmallLaunch<8>::CALL(g, w, r, st);  \
+	case 16: return SmallLaunch<16>::CALL(g, w, r, st);\
+	case 32: return SmallLaunch<32>::CALL(g, w, r, st);\
+	default: return hipErrorInvalidValue;              \
+	}
+
+hipError_t nbl_launch_cn_ems_small(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st) { NBL_DISPATCH_SMALL(g.q, ems) }
+hipError_t nbl_launch_cn_tems_small(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st) { NBL_DISPATCH_SMALL(g.q, tems) }
+hipError_t nbl_launch_cn_bp_small(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st) { NBL_DISPATCH_SMALL(g.q, bp) }

@@ -292,6 +292,92 @@ def test_tems_gf64_every_shape_ties_and_erasures_vs_oracle(oracle, codename, ite
     run(Li, dict(tems_nr=nr, tems_nc=nc, tems_factor=1.0, tems_offset=0.0), [oracle.CANONICAL, oracle.LITERAL])
 
 
+SMALL_CODES = ["divsalar.UNBLDPC.256.128.GF.16", "divsalar.UNBLDPC.128.64.GF.16"]  # check degrees 4 / 5 mixed; all 5
+
+
+def _small_field_inputs(rng, N, q):
+    Lr = rng.normal(-2, 4, (4, N, q - 1))
+    Lr[1, ::3] = 0.0                                    # erased symbols
+    Lr[2] = 0.0                                         # everything ties
+    Li = np.round(rng.normal(-1, 2, (4, N, q - 1)))     # integer-valued: exact ties everywhere
+    Li[1] = np.where(rng.random((N, q - 1)) < 0.8, -2.0, 3.0)
+    Li[2, ::2] = 0.0
+    return Lr, Li
+
+
+def _run_vs_oracle(oracle, codename, method, omethod, iters, L, kw, modes, exact=True):
+    code = nb.Code(codename)
+    N, M, q, ev, ec, eh = df.code_edges(codename)
+    refs = []
+    for mode in modes:
+        od = oracle.Decoder(oracle.Code(edges=(N, M, q, ev, ec, eh)), oracle.GF(q), omethod, iters, mode, **kw)
+        ref = []
+        for b in range(L.shape[0]):
+            r, o, it = od.decode(L[b])
+            ref.append((r, o.copy(), it, [x.copy() for x in od.state()]))
+        refs.append(ref)
+    for variant in (0, 1):  # 64 / q checks per wave (nbl_cn_small.hip); one check per wave (general kernels)
+        dec = nb.Decoder(code, method, iters, **kw)
+        _force_generic(dec, variant)
+        dec.record_state(True)
+        out, conv, its = dec.decode(L)
+        for ref in refs:
+            for b in range(L.shape[0]):
+                r, o, it, st = ref[b]
+                assert (conv[b], its[b]) == (r, it) and np.array_equal(out[b], o), (variant, b)
+                P, V, Cc = dec.read_state(b)
+                for a, x in zip((P, V, Cc), st):
+                    if exact:
+                        assert np.array_equal(a, x), (variant, b)
+                    else:
+                        assert np.max(np.abs(a - x)) <= LLR_TOL * max(1.0, np.max(np.abs(x))), (variant, b)
+        dec.close()
+
+
+@pytest.mark.parametrize("nm,nc", [(4, 1), (8, 1), (8, 2), (8, 3), (8, 4), (16, 3), (5, 2), (12, 4)])
+@pytest.mark.parametrize("codename", SMALL_CODES)
+def test_small_field_ems_every_shape_vs_oracle(oracle, codename, nm, nc):
+    """GF(16), four checks per wave (nbl_cn_small.hip) and the general one-check-per-wave kernel beside it: message state after
+    4 iterations bit-identical to the canonical oracle for every (nm, nc) -- plain convolution (nc >= dc - 1) and layered
+    deviation counting, checks of degree 4 and 5 inside one wave; integer-valued frames (exact ties in the ranking, in the
+    decisions) also against the LITERAL restatement, whose residue vanishes when every sum is exact."""
+    N, M, q, *_ = df.code_edges(codename)
+    Lr, Li = _small_field_inputs(np.random.default_rng(160 + 10 * nm + nc), N, q)
+    _run_vs_oracle(oracle, codename, nb.METHOD_EMS, oracle.EMS, 4, Lr, dict(ems_nm=nm, ems_nc=nc, ems_factor=1.15, ems_offset=0.2), [oracle.CANONICAL])
+    _run_vs_oracle(oracle, codename, nb.METHOD_EMS, oracle.EMS, 4, Li, dict(ems_nm=nm, ems_nc=nc, ems_factor=1.0, ems_offset=0.0),
+                   [oracle.CANONICAL, oracle.LITERAL])
+
+
+@pytest.mark.parametrize("nr,nc", [(1, 1), (2, 1), (2, 2), (2, 3), (3, 2), (3, 3), (5, 3)])
+@pytest.mark.parametrize("codename", SMALL_CODES)
+def test_small_field_tems_every_shape_vs_oracle(oracle, codename, nr, nc):
+    """As above for T-EMS: every (nr, nc) the kernels accept, shaped real-valued frames against the canonical oracle, integer
+    frames (column-order ties, path-code tie-break) against the canonical and the LITERAL one."""
+    N, M, q, *_ = df.code_edges(codename)
+    Lr, Li = _small_field_inputs(np.random.default_rng(1640 + 10 * nr + nc), N, q)
+    _run_vs_oracle(oracle, codename, nb.METHOD_TEMS, oracle.TEMS, 4, Lr, dict(tems_nr=nr, tems_nc=nc, tems_factor=1.1, tems_offset=0.15), [oracle.CANONICAL])
+    _run_vs_oracle(oracle, codename, nb.METHOD_TEMS, oracle.TEMS, 4, Li, dict(tems_nr=nr, tems_nc=nc, tems_factor=1.0, tems_offset=0.0),
+                   [oracle.CANONICAL, oracle.LITERAL])
+
+
+@pytest.mark.parametrize("codename", SMALL_CODES)
+def test_small_field_bp_vs_oracle(oracle, codename):
+    """log-QSPA on GF(16): decisions, flags and iteration counts equal the oracle's FP64 restatement, LLR state within 1e-9, for
+    ordinary frames, an all-zero frame and LLRs thousands of nats apart (the mantissa / exponent path).  No partially erased
+    frame here: a check with two erased edges sends LLRs that are zero up to rounding noise, and the hard decision of an erased
+    variable (hence the damping, :730-741) is then the sign of that noise -- the reference's 80-bit recursion, the oracle's FP64
+    one and the kernels' each have their own."""
+    N, M, q, *_ = df.code_edges(codename)
+    rng = np.random.default_rng(77)
+    L = rng.normal(-2, 4, (6, N, q - 1))
+    L[1] = rng.normal(-0.5, 1.0, (N, q - 1))
+    L[2] = 0.0
+    L[3] = rng.normal(-900, 700, (N, q - 1))
+    L[4] = rng.normal(-30000, 20000, (N, q - 1))
+    L[5] = rng.normal(-2, 3, (N, q - 1)) * np.where(rng.random((N, 1)) < 0.5, 1.0, 2000.0)  # narrow and wide vectors in one check
+    _run_vs_oracle(oracle, codename, nb.METHOD_BP, oracle.BP, 5, L, dict(), [oracle.CANONICAL], exact=False)
+
+
 def test_tems_gf256_nr3_nc2_integer_llr_regression(oracle):
     """Named regression guard: GF(256), nr = 3, nc = 2, integer LLRs -- the shape on which the first layout of the
     GF(256) T-EMS kernel's DP state produced wrong path codes at -O2/-O3 (nbl_cn_tems256.hip header; attributed to hipcc's late
