@@ -81,11 +81,10 @@ template <int Q> __device__ __forceinline__ Ctx<Q> ctx_init(const NblGraphDev &g
 // T-EMS (the steps and their reference lines are those of cn_tems_fast_kernel, nbl_cn_tems.hip; nc <= 3)
 // =====================================================================================================================
 struct __attribute__((aligned(16))) TState { double v[4]; unsigned c[4]; };
-struct __attribute__((aligned(16))) TCand { double u; int q; int pad; };
 
 __host__ __device__ inline size_t tems_small_group_bytes(int q, int mdc)
 {
-	const size_t n = (size_t)8 * (mdc * q + q) + (size_t)2 * q * sizeof(TState) + (size_t)mdc * (q + 4) * sizeof(TCand) + (size_t)4 * (2 * q + 2 * mdc);
+	const size_t n = (size_t)8 * (mdc * q + q) + (size_t)2 * q * sizeof(TState);
 	return (n + 15) & ~(size_t)15;
 }
 
@@ -101,17 +100,13 @@ __global__ __launch_bounds__(64) void cn_tems_small_kernel(NblGraphDev g, NblWor
 	double *dU = (double *)base;                 // [mdc][Q]
 	double *Lc = dU + mdc * Q;                   // [Q]
 	TState *st = (TState *)(Lc + Q);             // [2][Q] DP states (ping-pong)
-	TCand *cl = (TCand *)(st + 2 * Q);           // [mdc][Q+4] deviation candidates per column
-	int *ord01 = (int *)(cl + mdc * (Q + 4));    // [Q] first two columns of the per-symbol order
-	int *cmask = ord01 + Q;                      // [Q] bit d set: column d may deviate to this symbol
-	int *ccount = cmask + Q;                     // [mdc]
-	int *beta = ccount + mdc;                    // [mdc]
 
 	const double *V = w.v2c + (size_t)c.b * g.E * Q;
 	double *C = w.c2v + ((size_t)c.b * g.E + c0) * Q;
 
 	// ---- 1. beta, syndrome, dU (TEMS_Get_Beta :1789-1812, TEMS_Get_deltaU :1814-1834) -------------------------------
 	int syn = 0;
+	unsigned long long betas = 0; // beta_d, 8 bits each (group-uniform)
 	for (int d = 0; d < dc; d++) {
 		const double *Vd = V + (size_t)g.c_epos[c0 + d] * Q;
 		const double v = (sl > 0) ? Vd[sl] : 0.0;
@@ -121,55 +116,27 @@ __global__ __launch_bounds__(64) void cn_tems_small_kernel(NblGraphDev g, NblWor
 		const int arg = (mx > 0.0 && hit) ? __builtin_ctz(hit) : 0;
 		const uint8_t *mrow = g.mul + (size_t)g.c_h[c0 + d] * Q;
 		const int bd = mrow[arg]; // beta_d = h * argmax (0 if nothing positive)
-		if (sl == 0) beta[d] = bd;
+		betas |= (unsigned long long)bd << (8 * d);
 		syn ^= bd;
 		dU[d * Q + (mrow[sl] ^ bd)] = mx - v; // dU[d][h a ^ beta] = mx - L(a), L(0) = 0  (:1826-1831)
 	}
-	for (int d = sl; d < dc; d += Q) ccount[d] = 0;
 	WSYNC();
 
 	// ---- 2. per deviation symbol: stable ascending order of the columns, Nr smallest marked (TEMS_Get_Min :1836-1890) ----
-	{
-		int mask = 0, o0 = 0, o1 = 0;
-		for (int d = 0; d < dc; d++) {
-			const double ud = dU[d * Q + sl];
-			int rank = 0;
-			for (int e = 0; e < dc; e++) {
-				const double ue = dU[e * Q + sl];
-				rank += (ue < ud || (ue == ud && e < d)) ? 1 : 0;
-			}
-			if (rank < nr) mask |= 1 << d;
-			if (rank == 0) o0 = d;
-			if (rank == 1) o1 = d;
+	// the lane keeps what belongs to its own symbol: `mask` bit d = column d may deviate to it, o0 / o1 = first two columns
+	int mask = 0, o0 = 0, o1 = 0;
+	for (int d = 0; d < dc; d++) {
+		const double ud = dU[d * Q + sl];
+		int rank = 0;
+		for (int e = 0; e < dc; e++) {
+			const double ue = dU[e * Q + sl];
+			rank += (ue < ud || (ue == ud && e < d)) ? 1 : 0;
 		}
-		if (sl == 0) mask = (1 << dc) - 1;
-		cmask[sl] = mask;
-		ord01[sl] = o0 | (o1 << 8);
-		// candidate lists per column (non-zero symbols only; symbol 0 = "no deviation" is handled apart), packed {dU, symbol}
-		if (sl > 0) {
-			for (int d = 0; d < dc; d++)
-				if ((mask >> d) & 1) {
-					TCand e;
-					e.u = dU[d * Q + sl];
-					e.q = sl;
-					e.pad = 0;
-					cl[d * (Q + 4) + atomicAdd(&ccount[d], 1)] = e;
-				}
-		}
+		if (rank < nr) mask |= 1 << d;
+		if (rank == 0) o0 = d;
+		if (rank == 1) o1 = d;
 	}
-	WSYNC();
-	if (sl < 4) { // pad every list to a multiple of four with entries that can never win (cost +inf)
-		for (int d = 0; d < dc; d++) {
-			const int n = ccount[d];
-			if (n + sl < ((n + 3) & ~3)) {
-				TCand e;
-				e.u = __builtin_huge_val();
-				e.q = 0;
-				e.pad = 0;
-				cl[d * (Q + 4) + n + sl] = e;
-			}
-		}
-	}
+	if (sl == 0) mask = 0; // symbol 0 = "no deviation" is handled apart
 
 	// ---- 3. min-plus DP over the columns; all deviation-count layers advance together (TEMS_ConstructConf :1892-1944) ----
 	TState *A = st, *Bs = st + Q;
@@ -182,30 +149,27 @@ __global__ __launch_bounds__(64) void cn_tems_small_kernel(NblGraphDev g, NblWor
 	}
 	WSYNC();
 	for (int d = 0; d < dc; d++) {
-		const int n4 = (ccount[d] + 3) & ~3;
-		const TCand *L = cl + d * (Q + 4);
+		// the deviation symbols of column d as a bit set of the group (every order gives the same minimum and the same path code)
+		unsigned cand = gballot<Q>((mask >> d) & 1, c.gi);
 		TState b = A[sl]; // q_d = 0: dU[d][0] = 0 (:1826), cost unchanged
 #pragma unroll
 		for (int l = 0; l < 4; l++) { b.v[l] = b.v[l] + 0.0; b.c[l] = b.c[l] * Q; }
-		for (int k = 0; k < n4; k += 4) {
-			TCand e[4];
+		while (cand) {
+			const int q = __builtin_ctz(cand);
+			cand &= cand - 1;
+			const double u = dU[d * Q + q];
+			const TState src = A[sl ^ q];
 #pragma unroll
-			for (int u = 0; u < 4; u++) e[u] = L[k + u];
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const TState src = A[sl ^ e[u].q];
-#pragma unroll
-				for (int l = 1; l < 4; l++) {
-					if (l <= nc && l <= d + 1) { // a path through d+1 columns has at most d+1 deviations
-						const double val = src.v[l - 1] + e[u].u;
-						const unsigned code = src.c[l - 1] * Q + e[u].q;
-						// smaller cost wins, equal cost: smaller path code
-						const bool lt = val < b.v[l];
-						b.v[l] = lt ? val : b.v[l];
-						b.c[l] = lt ? code : b.c[l];
-						const unsigned cm = code < b.c[l] ? code : b.c[l];
-						b.c[l] = (val == b.v[l]) ? cm : b.c[l];
-					}
+			for (int l = 1; l < 4; l++) {
+				if (l <= nc && l <= d + 1) { // a path through d+1 columns has at most d+1 deviations
+					const double val = src.v[l - 1] + u;
+					const unsigned code = src.c[l - 1] * Q + q;
+					// smaller cost wins, equal cost: smaller path code
+					const bool lt = val < b.v[l];
+					b.v[l] = lt ? val : b.v[l];
+					b.c[l] = lt ? code : b.c[l];
+					const unsigned cm = code < b.c[l] ? code : b.c[l];
+					b.c[l] = (val == b.v[l]) ? cm : b.c[l];
 				}
 			}
 		}
@@ -235,13 +199,10 @@ __global__ __launch_bounds__(64) void cn_tems_small_kernel(NblGraphDev g, NblWor
 			__hip_atomic_fetch_min(&Lc[sl ^ dev], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 		WSYNC();
-		if (Lc[sl] == NBL_DBL_MAX) {                                             // never reached (:1095-1102)
-			const int o0 = ord01[sl] & 255, o1 = (ord01[sl] >> 8) & 255;
-			Lc[sl] = (d == o0) ? dU[o1 * Q + sl] : dU[o0 * Q + sl];
-		}
+		if (Lc[sl] == NBL_DBL_MAX) Lc[sl] = (d == o0) ? dU[o1 * Q + sl] : dU[o0 * Q + sl]; // never reached (:1095-1102)
 		WSYNC();
 		// delta domain -> LLR, un-permute by h (:1105-1127)
-		const int bsyn = syn ^ beta[d];
+		const int bsyn = syn ^ (int)((betas >> (8 * d)) & 255);
 		const double L0 = -1.0 * Lc[bsyn];
 		const uint8_t *mrow = g.mul + (size_t)g.c_h[c0 + d] * Q;
 		const int e = mrow[sl] ^ bsyn; // eta with h^-1 (eta ^ bsyn) = a
@@ -251,11 +212,13 @@ __global__ __launch_bounds__(64) void cn_tems_small_kernel(NblGraphDev g, NblWor
 }
 
 // =====================================================================================================================
-// EMS (max-plus dynamic programme of cn_ems_kernel, nbl_kernels.hip)
+// EMS (max-plus dynamic programme of cn_ems_kernel, nbl_kernels.hip; at most four deviation-count layers)
 // =====================================================================================================================
+struct __attribute__((aligned(16))) EmsEnt { double v; int t; int pad; }; // list entry: value, check-domain symbol
+
 __host__ __device__ inline size_t ems_small_group_bytes(int q, int mdc, int nm, int layers)
 {
-	const size_t n = (size_t)8 * ((size_t)mdc * q + (2 * (size_t)layers + 1) * q + (size_t)mdc * nm) + (size_t)4 * mdc * nm;
+	const size_t n = (size_t)8 * ((size_t)mdc * q + (2 * (size_t)layers + 1) * q) + (size_t)16 * mdc * nm;
 	return (n + 15) & ~(size_t)15;
 }
 
@@ -271,8 +234,7 @@ __global__ __launch_bounds__(64) void cn_ems_small_kernel(NblGraphDev g, NblWork
 	double *A0 = U + mdc * Q;          // [layers][Q] DP ping
 	double *B0 = A0 + layers * Q;      // [layers][Q] DP pong
 	double *Sv = B0 + layers * Q;      // [Q]        variable-domain copy for the ranking, then the maxima of the current output edge
-	double *lv = Sv + Q;               // [mdc][nm]  values of the nm most reliable entries, by rank (rank 0 first)
-	int *lt = (int *)(lv + mdc * nm);  // [mdc][nm]  their check-domain symbols
+	EmsEnt *ls = (EmsEnt *)(Sv + Q);   // [mdc][nm]  the nm most reliable entries of every edge, by rank (rank 0 first)
 
 	const double *V = w.v2c + (size_t)c.b * g.E * Q;
 	double *C = w.c2v + ((size_t)c.b * g.E + c0) * Q;
@@ -293,7 +255,13 @@ __global__ __launch_bounds__(64) void cn_ems_small_kernel(NblGraphDev g, NblWork
 			const double vo = Sv[x];
 			rank += (vo > v || (vo == v && x > sl)) ? 1 : 0;
 		}
-		if (rank < nm) { lv[j * nm + rank] = v; lt[j * nm + rank] = t; }
+		if (rank < nm) {
+			EmsEnt e;
+			e.v = v;
+			e.t = t;
+			e.pad = 0;
+			ls[j * nm + rank] = e;
+		}
 	}
 	WSYNC();
 
@@ -302,16 +270,16 @@ __global__ __launch_bounds__(64) void cn_ems_small_kernel(NblGraphDev g, NblWork
 #define OTH(l) ((l) + ((l) >= x ? 1 : 0))
 		const int rn = dc - 1;
 		int zall = 0;
-		for (int l = 0; l < rn; l++) zall ^= lt[OTH(l) * nm];
+		for (int l = 0; l < rn; l++) zall ^= ls[OTH(l) * nm].t;
 		double S = -NBL_DBL_MAX;
 
 		// conf(q,1): at most one edge deviates, to ANY symbol (:894)
 		for (int pi = 0; pi < rn; pi++) {
 			const int jd = OTH(pi);
-			const int shift = zall ^ lt[jd * nm];
+			const int shift = zall ^ ls[jd * nm].t;
 			const double u = U[jd * Q + (sl ^ shift)];
 			double acc = 0.0;
-			for (int l = 0; l < rn; l++) acc = acc + ((l == pi) ? u : lv[OTH(l) * nm]);
+			for (int l = 0; l < rn; l++) acc = acc + ((l == pi) ? u : ls[OTH(l) * nm].v);
 			S = dmax(S, acc);
 		}
 
@@ -324,20 +292,23 @@ __global__ __launch_bounds__(64) void cn_ems_small_kernel(NblGraphDev g, NblWork
 			WSYNC();
 			if (rn == 1) {
 				const int j1 = OTH(0);
-				for (int k = sl; k < nm; k += Q) A[lt[j1 * nm + k]] = 0.0 + lv[j1 * nm + k];
+				for (int k = sl; k < nm; k += Q) A[ls[j1 * nm + k].t] = 0.0 + ls[j1 * nm + k].v;
 			} else {
 				const int j1 = OTH(0), j2 = OTH(1);
 				for (int idx = sl; idx < nm * nm; idx += Q) {
 					const int k1 = idx / nm, k2 = idx - k1 * nm;
-					const double val = (0.0 + lv[j1 * nm + k1]) + lv[j2 * nm + k2];
-					__hip_atomic_fetch_max(&A[lt[j1 * nm + k1] ^ lt[j2 * nm + k2]], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					const EmsEnt e1 = ls[j1 * nm + k1], e2 = ls[j2 * nm + k2];
+					__hip_atomic_fetch_max(&A[e1.t ^ e2.t], (0.0 + e1.v) + e2.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
 			}
 			WSYNC();
 			for (int l = 2; l < rn; l++) {
 				const int jl = OTH(l);
 				double acc = NBL_NEG_INF;
-				for (int k = 0; k < nm; k++) acc = dmax(acc, A[sl ^ lt[jl * nm + k]] + lv[jl * nm + k]);
+				for (int k = 0; k < nm; k++) {
+					const EmsEnt e = ls[jl * nm + k];
+					acc = dmax(acc, A[sl ^ e.t] + e.v);
+				}
 				if (l == rn - 1) S = dmax(S, acc);
 				else {
 					Bq[sl] = acc;
@@ -347,24 +318,45 @@ __global__ __launch_bounds__(64) void cn_ems_small_kernel(NblGraphDev g, NblWork
 			}
 			if (rn <= 2) S = dmax(S, A[sl]);
 		} else {
-			// layered DP: A[d][s] = best value reaching check sum s with exactly d deviations
-			for (int d = 0; d < layers; d++) A[d * Q + sl] = (d == 0 && sl == 0) ? 0.0 : NBL_NEG_INF;
+			// layered DP: A[d][s] = best value reaching check sum s with exactly d deviations.  After the first other edge this is
+			// layer 0 = {z: 0 + rank-0 value}, layer 1 = {t_k: 0 + v_k, k >= 1} (what the general kernel's first step computes from
+			// the start state {0: 0}); after l edges no path has more than l deviations, so layer d is only touched for d <= l + 1.
+			for (int d = 0; d < layers; d++) A[d * Q + sl] = NBL_NEG_INF;
 			WSYNC();
-			for (int l = 0; l < rn; l++) {
-				const int jl = OTH(l);
-				const int z = lt[jl * nm];
-				const double mz = lv[jl * nm];
-				for (int d = 0; d < layers; d++) {
-					double acc = A[d * Q + (sl ^ z)] + mz;
-					// after l edges no path has more than l deviations: layer d-1 is still all -inf for d - 1 > l
-					if (d >= 1 && d <= l + 1)
-						for (int k = 1; k < nm; k++) acc = dmax(acc, A[(d - 1) * Q + (sl ^ lt[jl * nm + k])] + lv[jl * nm + k]);
-					Bq[d * Q + sl] = acc;
+			{
+				const int j0 = OTH(0);
+				for (int k = sl; k < nm; k += Q) {
+					const EmsEnt e = ls[j0 * nm + k];
+					A[(k == 0 ? 0 : Q) + e.t] = 0.0 + e.v;
 				}
-				WSYNC();
-				double *T = A; A = Bq; Bq = T;
 			}
-			for (int d = 0; d < layers; d++) S = dmax(S, A[d * Q + sl]);
+			WSYNC();
+			for (int l = 1; l < rn; l++) {
+				const int jl = OTH(l);
+				const EmsEnt top = ls[jl * nm];
+				double acc[4];
+#pragma unroll
+				for (int d = 0; d < 4; d++) acc[d] = (d < layers) ? A[d * Q + (sl ^ top.t)] + top.v : NBL_NEG_INF;
+				for (int k = 1; k < nm; k++) {
+					const EmsEnt e = ls[jl * nm + k];
+#pragma unroll
+					for (int d = 1; d < 4; d++)
+						if (d < layers && d <= l + 1) acc[d] = dmax(acc[d], A[(d - 1) * Q + (sl ^ e.t)] + e.v);
+				}
+				if (l == rn - 1) {
+#pragma unroll
+					for (int d = 0; d < 4; d++)
+						if (d < layers) S = dmax(S, acc[d]);
+				} else {
+#pragma unroll
+					for (int d = 0; d < 4; d++)
+						if (d < layers) Bq[d * Q + sl] = acc[d];
+					WSYNC();
+					double *T = A; A = Bq; Bq = T;
+				}
+			}
+			if (rn == 1)
+				for (int d = 0; d < layers; d++) S = dmax(S, A[d * Q + sl]);
 		}
 
 		// ---- output: c2v[a] = shape(S[h_x a] - S[0]) (:899-916) ------------------------------------------------------------
@@ -579,7 +571,7 @@ bool nbl_small_applicable(const NblGraphDev &g, int method, int min_dc, int nm, 
 {
 	if (g.q > 32 || g.q < 4 || min_dc < 3 || g.maxdc > NBL_MAXDC) return false;
 	const int G = 64 / g.q;
-	if (method == 2) return ems_small_group_bytes(g.q, g.maxdc, nm, nbl_ems_layers(g, nc)) * G <= 64 * 1024;
+	if (method == 2) return nbl_ems_layers(g, nc) <= 4 && ems_small_group_bytes(g.q, g.maxdc, nm, nbl_ems_layers(g, nc)) * G <= 64 * 1024;
 	if (method == 4) return nc <= 3 && g.p * g.maxdc <= 32 && tems_small_group_bytes(g.q, g.maxdc) * G <= 64 * 1024;
 	if (method == 1) return bp_small_group_bytes(g.q, g.maxdc) * G <= 64 * 1024;
 	return false;
