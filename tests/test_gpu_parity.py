@@ -378,6 +378,83 @@ def test_small_field_bp_vs_oracle(oracle, codename):
     _run_vs_oracle(oracle, codename, nb.METHOD_BP, oracle.BP, 5, L, dict(), [oracle.CANONICAL], exact=False)
 
 
+def _random_code(q, seed, M=12, degs=(3, 4, 5, 6)):
+    """Synthetic irregular graph: check degrees cycle through `degs`, variables of degree 2 and 3 on distinct checks.  Returns
+    (nb.Code, oracle edge tuple); the check-major edge order is the one the oracle derives from the variable-major list."""
+    rng = np.random.default_rng(seed)
+    for _ in range(200):
+        sockets = [m for m in range(M) for _ in range(degs[m % len(degs)])]
+        rng.shuffle(sockets)
+        rows, ok = [], True
+        while sockets:
+            dv = 3 if (len(rows) % 3 == 2 and len(sockets) != 4) else 2
+            if len(sockets) < dv or len(sockets) - dv == 1:
+                dv = len(sockets)
+            pick = sockets[:dv]
+            if len(set(pick)) != dv or dv < 2 or dv > 3:
+                ok = False
+                break
+            rows.append(sorted(pick))
+            sockets = sockets[dv:]
+        if ok:
+            break
+    assert ok
+    N = len(rows)
+    var_rows = [[(m + 1, int(rng.integers(1, q))) for m in r] for r in rows]
+    chk_rows = [[] for _ in range(M)]
+    ev, ec, eh = [], [], []
+    for n, r in enumerate(var_rows):
+        for m1, h in r:
+            chk_rows[m1 - 1].append((n + 1, h))
+            ev.append(n); ec.append(m1 - 1); eh.append(h)
+    code = nb.Code(spec=dict(N=N, M=M, q=q, var_rows=var_rows, chk_rows=chk_rows))
+    return code, (N, M, q, np.array(ev, np.int32), np.array(ec, np.int32), np.array(eh, np.int32))
+
+
+@pytest.mark.parametrize("method", ["ems", "ems_plain", "tems", "bp"])
+@pytest.mark.parametrize("q", [4, 8, 32, 128])
+def test_field_sizes_without_a_shipped_code(oracle, q, method):
+    """GF(4), GF(8), GF(32) (16 / 8 / 2 checks per wave in nbl_cn_small.hip) and GF(128) (general kernels, two symbols per lane)
+    have no shipped code: synthetic irregular graphs (check degrees 3-6, variable degrees 2-3), every method, both kernel
+    families against the oracle -- EMS / T-EMS bit for bit on real-valued and on integer (tie-heavy) frames, log-QSPA within 1e-9.
+    (log-QSPA runs 3 iterations here: these 12-check graphs are full of 4-cycles, and with LLRs hundreds of nats apart the
+    box-plus is a max-plus sum, so from iteration 4 on a variable's own L_ch comes back with the opposite sign -- v2c entries that
+    are zero up to rounding noise, whose sign then decides the damping (:730-741) differently in every implementation.)"""
+    code, edges = _random_code(q, 900 + q, degs=(3, 4, 5, 6) if q <= 32 else (3, 4))  # (T-EMS path code: p * maxdc <= 32 bits)
+    N = code.N
+    rng = np.random.default_rng(q)
+    L = rng.normal(-1.5, 3, (5, N, q - 1))
+    L[3] = np.round(rng.normal(-1, 2, (N, q - 1)))
+    L[4] = 0.0
+    if method == "bp":
+        L = L[[0, 1, 2, 4]]
+        L[2] = rng.normal(-800, 600, (N, q - 1))
+    meth, ometh, kw = {"ems": (nb.METHOD_EMS, oracle.EMS, dict(ems_nm=min(q, 6), ems_nc=2, ems_factor=1.1, ems_offset=0.1)),
+                       "ems_plain": (nb.METHOD_EMS, oracle.EMS, dict(ems_nm=min(q, 5), ems_nc=5, ems_factor=1.0, ems_offset=0.0)),
+                       "tems": (nb.METHOD_TEMS, oracle.TEMS, dict(tems_nr=2, tems_nc=3 if q <= 32 else 2, tems_factor=1.0, tems_offset=0.0)),
+                       "bp": (nb.METHOD_BP, oracle.BP, dict())}[method]
+    iters = 3 if method == "bp" else 4
+    od = oracle.Decoder(oracle.Code(edges=edges), oracle.GF(q), ometh, iters, oracle.CANONICAL, **kw)
+    ref = []
+    for b in range(L.shape[0]):
+        r, o, it = od.decode(L[b])
+        ref.append((r, o.copy(), it, [x.copy() for x in od.state()]))
+    for variant in (0, 1):
+        dec = nb.Decoder(code, meth, iters, **kw)
+        _force_generic(dec, variant)
+        dec.record_state(True)
+        out, conv, its = dec.decode(L)
+        for b in range(L.shape[0]):
+            r, o, it, st = ref[b]
+            assert (conv[b], its[b]) == (r, it) and np.array_equal(out[b], o), (variant, b)
+            for a, x in zip(dec.read_state(b), st):
+                if method == "bp":
+                    assert np.max(np.abs(a - x)) <= LLR_TOL * max(1.0, np.max(np.abs(x))), (variant, b)
+                else:
+                    assert np.array_equal(a, x), (variant, b)
+        dec.close()
+
+
 def test_tems_gf256_nr3_nc2_integer_llr_regression(oracle):
     """Named regression guard: GF(256), nr = 3, nc = 2, integer LLRs -- the shape on which the first layout of the
     GF(256) T-EMS kernel's DP state produced wrong path codes at -O2/-O3 (nbl_cn_tems256.hip header; attributed to hipcc's late
