@@ -136,8 +136,26 @@ static void free_workspace(nbl_decoder *d)
 
 // Shapes whose whole iteration is ONE launch (variable-node pass recomputed inside the check-node kernel, c2v double-buffered):
 // (2,4)-regular codes, EMS over GF(256) with nm in {8,16,32}, T-EMS over GF(64) and GF(256), log-QSPA over GF(256).
+static bool small_enabled()
+{
+	static const bool on = !getenv("NBL_NO_SMALL"); // A/B measurements: the one-check-per-wave kernels on small fields
+	return on;
+}
+
+// small fields (q <= 32): 64 / q checks per wave, any variable degree (nbl_cn_small.hip)
+static bool small_shape(const nbl_decoder *d)
+{
+	if (!small_enabled()) return false;
+	const nbl_params &p = d->prm;
+	if (p.method == NBL_METHOD_EMS) return nbl_small_applicable(d->g, p.method, d->min_dc, p.ems_nm, p.ems_nc);
+	if (p.method == NBL_METHOD_TEMS) return nbl_small_applicable(d->g, p.method, d->min_dc, 0, p.tems_nc);
+	if (p.method == NBL_METHOD_BP) return nbl_small_applicable(d->g, p.method, d->min_dc, 0, 0);
+	return false;
+}
+
 static bool fused_shape(const nbl_decoder *d)
 {
+	if (small_shape(d)) return d->g.c_nbr != nullptr; // (variable degrees above 3: the small kernels behind the separate VN pass)
 	if (!d->all_dv2) return false;
 	if (d->prm.method == NBL_METHOD_EMS) return nbl_ems256_applicable(d->g, d->all_dc4, d->prm.ems_nm, d->prm.ems_nc);
 	if (d->prm.method == NBL_METHOD_TEMS)
@@ -310,6 +328,16 @@ extern "C" nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_m
 			}
 		if ((st = upload(d, toff, &d->g.ems_toff))) return fail_create(d, st, "");
 	}
+	if (q <= 32 && maxdv <= 3) {
+		// fused small-field iteration: everything the variable-node stage of a check-major edge needs, in one 16-byte row
+		std::vector<int> nbr((size_t)E * 4);
+		for (int ce = 0; ce < E; ce++) {
+			const int n = c_var[ce], e0 = voff[n], dv = voff[n + 1] - e0;
+			for (int k = 0; k < 3; k++) nbr[(size_t)ce * 4 + k] = k < dv ? v_cpos[e0 + k] : -1;
+			nbr[(size_t)ce * 4 + 3] = (c_epos[ce] == e0) ? 1 : 0;
+		}
+		if ((st = upload(d, nbr, &d->g.c_nbr))) return fail_create(d, st, "");
+	}
 	void *cnt = nullptr;
 	if (hipMalloc(&cnt, 16) != hipSuccess) return fail_create(d, NBL_ERR_NOMEM, "hipMalloc failed");
 	d->graph_allocs.push_back(cnt);
@@ -409,22 +437,22 @@ extern "C" nbl_status nbl_last_timing(nbl_decoder *d, double ms[4], int64_t laun
 
 static nbl_status launch_cn(nbl_decoder *d, const NblRun &r, hipStream_t st)
 {
-	static const bool small_on = !getenv("NBL_NO_SMALL"); // A/B measurements: the one-check-per-wave kernels on small fields
+	const bool small_on = small_shape(d);
 	switch (d->prm.method) {
 	case NBL_METHOD_EMS:
 		if (d->force_generic != 1 && nbl_ems256_applicable(d->g, d->all_dc4, r.nm, r.nc)) HIP_TRY(d, nbl_launch_cn_ems256(d->g, d->w, r, false, st));
-		else if (d->force_generic != 1 && small_on && nbl_small_applicable(d->g, NBL_METHOD_EMS, d->min_dc, r.nm, r.nc)) HIP_TRY(d, nbl_launch_cn_ems_small(d->g, d->w, r, st));
+		else if (d->force_generic != 1 && small_on) HIP_TRY(d, nbl_launch_cn_ems_small(d->g, d->w, r, false, st));
 		else HIP_TRY(d, nbl_launch_cn_ems(d->g, d->w, r, st));
 		break;
 	case NBL_METHOD_TEMS:
 		if (d->force_generic != 1 && nbl_tems64_applicable(d->g, d->all_dc4, r.nr, r.nc)) HIP_TRY(d, nbl_launch_cn_tems64(d->g, d->w, r, false, st));
 		else if (d->force_generic != 1 && nbl_tems256_applicable(d->g, d->all_dc4, r.nr, r.nc)) HIP_TRY(d, nbl_launch_cn_tems256(d->g, d->w, r, false, st));
-		else if (d->force_generic != 1 && small_on && nbl_small_applicable(d->g, NBL_METHOD_TEMS, d->min_dc, 0, r.nc)) HIP_TRY(d, nbl_launch_cn_tems_small(d->g, d->w, r, st));
+		else if (d->force_generic != 1 && small_on) HIP_TRY(d, nbl_launch_cn_tems_small(d->g, d->w, r, false, st));
 		else HIP_TRY(d, nbl_launch_cn_tems(d->g, d->w, r, st));
 		break;
 	case NBL_METHOD_BP:
 		if (d->force_generic != 1 && nbl_bp256_applicable(d->g, d->all_dc4)) HIP_TRY(d, nbl_launch_cn_bp256(d->g, d->w, r, false, st));
-		else if (d->force_generic != 1 && small_on && nbl_small_applicable(d->g, NBL_METHOD_BP, d->min_dc, 0, 0)) HIP_TRY(d, nbl_launch_cn_bp_small(d->g, d->w, r, st));
+		else if (d->force_generic != 1 && small_on) HIP_TRY(d, nbl_launch_cn_bp_small(d->g, d->w, r, false, st));
 		else HIP_TRY(d, nbl_launch_cn_bp(d->g, d->w, r, st));
 		break;
 	default: d->err = "check-node kernel for this method is not built yet"; return NBL_ERR_UNSUPPORTED;
@@ -469,7 +497,11 @@ static nbl_status enqueue_window(IterCtx &c, int it_lo, int it_hi, hipStream_t s
 			wf.c2v_prev = (it == 1 && c.zeros) ? c.zeros : (it & 1) ? c.bufA : c.bufB;
 			wf.c2v = (it & 1) ? c.bufB : c.bufA;
 			wf.store_v2c = d->record_state ? 1 : 0;
-			if (p.method == NBL_METHOD_EMS) HIP_TRY(d, nbl_launch_cn_ems256(d->g, wf, c.r, true, st));
+			if (d->g.q <= 32) {
+				if (p.method == NBL_METHOD_EMS) HIP_TRY(d, nbl_launch_cn_ems_small(d->g, wf, c.r, true, st));
+				else if (p.method == NBL_METHOD_TEMS) HIP_TRY(d, nbl_launch_cn_tems_small(d->g, wf, c.r, true, st));
+				else HIP_TRY(d, nbl_launch_cn_bp_small(d->g, wf, c.r, true, st));
+			} else if (p.method == NBL_METHOD_EMS) HIP_TRY(d, nbl_launch_cn_ems256(d->g, wf, c.r, true, st));
 			else if (p.method == NBL_METHOD_TEMS && d->g.q == 64) HIP_TRY(d, nbl_launch_cn_tems64(d->g, wf, c.r, true, st));
 			else if (p.method == NBL_METHOD_TEMS) HIP_TRY(d, nbl_launch_cn_tems256(d->g, wf, c.r, true, st));
 			else HIP_TRY(d, nbl_launch_cn_bp256(d->g, wf, c.r, true, st));

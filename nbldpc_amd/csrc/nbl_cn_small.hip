@@ -77,6 +77,98 @@ template <int Q> __device__ __forceinline__ Ctx<Q> ctx_init(const NblGraphDev &g
 	return c;
 }
 
+// DecideLLRVector (:1542-1562) inside the group: lowest symbol among the maxima of {0, v}; v of symbol 0 must be <= 0
+template <int Q> __device__ __forceinline__ int gdecide(double v, int gi)
+{
+	const double mx = dmax(gmax_f64<Q>(v), 0.0);
+	const unsigned hit = gballot<Q>(v == mx, gi);
+	return (mx > 0.0 && hit) ? __builtin_ctz(hit) : 0;
+}
+
+// The dc incoming vectors of the group's check, handed to `stage(d, v)` edge by edge (v = the lane's symbol of v2c_d, 0 for
+// symbol 0).  FOUR EDGES AT A TIME: every global load of a chunk -- indices first, then data -- is issued before the first value
+// is used, because the stage bodies are chains of LDS phases behind fences that no load can be hoisted over.
+//
+// FUSED (one launch = a whole flooding iteration, c2v double-buffered, variable degrees <= 3): the variable-node pass of a
+// check-major edge is recomputed from the previous iteration's c2v by the group that needs the message -- a-posteriori sum
+// L_ch + c2v_0 + c2v_1 (+ c2v_2) in edge order (:676-691 / :808-823 / :977-992), hard decision written by the check that holds
+// the variable's first edge, v2c = post - c2v of this edge, and for the damped methods (DAMP: log-QSPA 1/2 : 1/2 :730-741,
+// T-EMS 1/4 : 3/4 :1029-1052) the blend with the previous v2c when the message's hard decision moved.  The previous decision is
+// what this stage recorded one iteration ago (w.edge_dec), as in the GF(256) kernels; g.c_nbr holds the c2v slots of the
+// variable's edges, so the data loads are one index load deep.
+// The values of a chunk wait in `vin` ([4][Q] doubles of the group's LDS region), so the stage body exists once in the code.
+template <int Q, bool FUSED, bool DAMP, class Stage>
+__device__ __forceinline__ void for_each_input(const NblGraphDev &g, const NblWork &w, const NblRun &r, const Ctx<Q> &c, double *vin, Stage &&stage)
+{
+	const int sl = c.sl, dc = c.dc, c0 = c.c0;
+	for (int base = 0; base < dc; base += 4) {
+		if (!FUSED) {
+			const double *V = w.v2c + (size_t)c.b * g.E * Q;
+			double v[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int d = (base + u < dc) ? base + u : 0;
+				v[u] = V[(size_t)g.c_epos[c0 + d] * Q + sl];
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) vin[u * Q + sl] = (sl > 0) ? v[u] : 0.0;
+		} else {
+			const double *Cp = w.c2v_prev + (size_t)c.b * g.E * Q;
+			int4 row[4];
+			int n[4], e[4], before[4];
+			double L[4], x0[4], x1[4], x2[4], ov[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int ce = c0 + ((base + u < dc) ? base + u : 0);
+				row[u] = ((const int4 *)g.c_nbr)[ce];
+				n[u] = g.c_var[ce];
+				e[u] = g.c_epos[ce];
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				L[u] = w.Lch[((size_t)c.b * g.N + n[u]) * Q + sl];
+				x0[u] = Cp[(size_t)row[u].x * Q + sl];
+				x1[u] = Cp[(size_t)row[u].y * Q + sl];
+				x2[u] = Cp[(size_t)(row[u].z >= 0 ? row[u].z : row[u].x) * Q + sl];
+				if (DAMP) {
+					ov[u] = w.v2c[((size_t)c.b * g.E + e[u]) * Q + sl];
+					before[u] = (r.iter > 1) ? w.edge_dec[(size_t)c.b * g.E + e[u]] : 0;
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				if (base + u < dc) {
+					const int ce = c0 + base + u;
+					double post = (L[u] + x0[u]) + x1[u];
+					post = (row[u].z >= 0) ? post + x2[u] : post;
+					double nv = post - ((row[u].x == ce) ? x0[u] : (row[u].y == ce) ? x1[u] : x2[u]);
+					if (row[u].w) { // the variable's first edge: this check reports the hard decision (and the a-posteriori vector)
+						const int dec = gdecide<Q>(post, c.gi);
+						if (sl == 0) w.dec[(size_t)c.b * g.N + n[u]] = dec;
+						if (w.post) w.post[((size_t)c.b * g.N + n[u]) * Q + sl] = post;
+					}
+					if (DAMP) {
+						// iteration 1: the previous v2c is L_ch (init kernel), nothing has been recorded yet
+						const int bf = (r.iter == 1) ? gdecide<Q>(ov[u], c.gi) : before[u];
+						int after = gdecide<Q>(nv, c.gi);
+						if (bf != after) {
+							nv = __dadd_rn(__dmul_rn(r.damp_old, ov[u]), __dmul_rn(r.damp_new, nv));
+							after = gdecide<Q>((sl == 0) ? 0.0 : nv, c.gi);
+						}
+						if (sl == 0) w.edge_dec[(size_t)c.b * g.E + e[u]] = after;
+						w.v2c[((size_t)c.b * g.E + e[u]) * Q + sl] = (sl == 0) ? 0.0 : nv;
+					} else if (w.store_v2c) {
+						w.v2c[((size_t)c.b * g.E + e[u]) * Q + sl] = (sl == 0) ? 0.0 : nv;
+					}
+					vin[u * Q + sl] = (sl == 0) ? 0.0 : nv;
+				}
+			}
+		}
+#pragma unroll 1
+		for (int u = 0; u < 4 && base + u < dc; u++) stage(base + u, vin[u * Q + sl]);
+	}
+}
+
 // =====================================================================================================================
 // T-EMS (the steps and their reference lines are those of cn_tems_fast_kernel, nbl_cn_tems.hip; nc <= 3)
 // =====================================================================================================================
@@ -88,8 +180,8 @@ __host__ __device__ inline size_t tems_small_group_bytes(int q, int mdc)
 	return (n + 15) & ~(size_t)15;
 }
 
-template <int Q>
-__global__ __launch_bounds__(64) void cn_tems_small_kernel(NblGraphDev g, NblWork w, NblRun r)
+template <int Q, bool FUSED>
+__global__ __launch_bounds__(64, 4) void cn_tems_small_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	constexpr int P = Fld<Q>::P;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -100,16 +192,14 @@ __global__ __launch_bounds__(64) void cn_tems_small_kernel(NblGraphDev g, NblWor
 	double *dU = (double *)base;                 // [mdc][Q]
 	double *Lc = dU + mdc * Q;                   // [Q]
 	TState *st = (TState *)(Lc + Q);             // [2][Q] DP states (ping-pong)
+	double *vin = (double *)st;                  // [4][Q] the incoming values of a chunk of edges (before the DP starts)
 
-	const double *V = w.v2c + (size_t)c.b * g.E * Q;
 	double *C = w.c2v + ((size_t)c.b * g.E + c0) * Q;
 
 	// ---- 1. beta, syndrome, dU (TEMS_Get_Beta :1789-1812, TEMS_Get_deltaU :1814-1834) -------------------------------
 	int syn = 0;
 	unsigned long long betas = 0; // beta_d, 8 bits each (group-uniform)
-	for (int d = 0; d < dc; d++) {
-		const double *Vd = V + (size_t)g.c_epos[c0 + d] * Q;
-		const double v = (sl > 0) ? Vd[sl] : 0.0;
+	for_each_input<Q, FUSED, true>(g, w, r, c, vin, [&](int d, double v) {
 		// most reliable symbol: strict '>' over ascending symbols from a running maximum of 0 (:1798-1807)
 		const double mx = dmax(gmax_f64<Q>(v), 0.0);
 		const unsigned hit = gballot<Q>(v == mx, c.gi);
@@ -119,7 +209,7 @@ __global__ __launch_bounds__(64) void cn_tems_small_kernel(NblGraphDev g, NblWor
 		betas |= (unsigned long long)bd << (8 * d);
 		syn ^= bd;
 		dU[d * Q + (mrow[sl] ^ bd)] = mx - v; // dU[d][h a ^ beta] = mx - L(a), L(0) = 0  (:1826-1831)
-	}
+	});
 	WSYNC();
 
 	// ---- 2. per deviation symbol: stable ascending order of the columns, Nr smallest marked (TEMS_Get_Min :1836-1890) ----
@@ -218,12 +308,13 @@ struct __attribute__((aligned(16))) EmsEnt { double v; int t; int pad; }; // lis
 
 __host__ __device__ inline size_t ems_small_group_bytes(int q, int mdc, int nm, int layers)
 {
-	const size_t n = (size_t)8 * ((size_t)mdc * q + (2 * (size_t)layers + 1) * q) + (size_t)16 * mdc * nm;
+	const size_t dp = 2 * (size_t)layers > 4 ? 2 * (size_t)layers : 4; // DP ping + pong; the staging of a chunk of inputs aliases them
+	const size_t n = (size_t)8 * ((size_t)mdc * q + (dp + 1) * q) + (size_t)16 * mdc * nm;
 	return (n + 15) & ~(size_t)15;
 }
 
-template <int Q>
-__global__ __launch_bounds__(64) void cn_ems_small_kernel(NblGraphDev g, NblWork w, NblRun r, int layers)
+template <int Q, bool FUSED>
+__global__ __launch_bounds__(64, 4) void cn_ems_small_kernel(NblGraphDev g, NblWork w, NblRun r, int layers)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const Ctx<Q> c = ctx_init<Q>(g, w, r);
@@ -233,16 +324,14 @@ __global__ __launch_bounds__(64) void cn_ems_small_kernel(NblGraphDev g, NblWork
 	double *U = (double *)base;        // [mdc][Q]   check-domain input vectors: U[j][h_j*a] = v2c_j[a], U[j][0] = 0
 	double *A0 = U + mdc * Q;          // [layers][Q] DP ping
 	double *B0 = A0 + layers * Q;      // [layers][Q] DP pong
-	double *Sv = B0 + layers * Q;      // [Q]        variable-domain copy for the ranking, then the maxima of the current output edge
+	double *vin = A0;                  // [4][Q]     the incoming values of a chunk of edges (before the DP starts; >= 4 vectors there)
+	double *Sv = A0 + (2 * layers > 4 ? 2 * layers : 4) * Q; // [Q] variable-domain copy for the ranking, then the maxima of the current output edge
 	EmsEnt *ls = (EmsEnt *)(Sv + Q);   // [mdc][nm]  the nm most reliable entries of every edge, by rank (rank 0 first)
 
-	const double *V = w.v2c + (size_t)c.b * g.E * Q;
 	double *C = w.c2v + ((size_t)c.b * g.E + c0) * Q;
 
 	// ---- stage the dc incoming vectors: permute into the check domain, rank, keep the nm best ---------------------------
-	for (int j = 0; j < dc; j++) {
-		const double *Vj = V + (size_t)g.c_epos[c0 + j] * Q;
-		const double v = (sl > 0) ? Vj[sl] : 0.0;
+	for_each_input<Q, FUSED, false>(g, w, r, c, vin, [&](int j, double v) {
 		const int t = g.mul[(size_t)g.c_h[c0 + j] * Q + sl];
 		U[j * Q + t] = v;
 		WSYNC();
@@ -262,7 +351,7 @@ __global__ __launch_bounds__(64) void cn_ems_small_kernel(NblGraphDev g, NblWork
 			e.pad = 0;
 			ls[j * nm + rank] = e;
 		}
-	}
+	});
 	WSYNC();
 
 	// ---- one output edge at a time -----------------------------------------------------------------------------------------
@@ -468,7 +557,7 @@ template <int Q> __device__ __forceinline__ double lse_conv_small(const SVec &A,
 	return (sl == 0) ? 0.0 : lse - norm;
 }
 
-template <int Q>
+template <int Q, bool FUSED>
 __global__ __launch_bounds__(64) void cn_bp_small_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -483,22 +572,21 @@ __global__ __launch_bounds__(64) void cn_bp_small_kernel(NblGraphDev g, NblWork 
 	s.Pb = s.Pa + Q;
 	s.T = s.Pb + Q;
 	s.Ve = (int *)(s.T + Q);
+	double *vin = s.Vm + mdc * Q; // [min(4, mdc)][Q] the incoming values of a chunk of edges (the F slots are empty until all inputs are in)
 	s.Ea = s.Ve + nv * Q;
 	s.Eb = s.Ea + Q;
 
-	const double *V = w.v2c + (size_t)c.b * g.E * Q;
 	double *C = w.c2v + ((size_t)c.b * g.E + c0) * Q;
 
 	// inputs into the check domain: p_d[h_d a] = v2c_d[a], symbol 0 = LLR 0 (the A1 == 0 branch of LLR_BoxPlus, :1623-1632);
 	// vector slots: p_d -> d, F_k (k = 2..dc-2) -> mdc + k - 2, the running R -> 2 mdc - 2 + (0 | 1)
-	for (int d = 0; d < dc; d++) {
-		const double *Vd = V + (size_t)g.c_epos[c0 + d] * Q;
+	for_each_input<Q, FUSED, true>(g, w, r, c, vin, [&](int d, double v) {
 		const int t = g.mul[(size_t)g.c_h[c0 + d] * Q + sl];
 		WSYNC();
-		s.T[t] = (sl == 0) ? 0.0 : Vd[sl];
+		s.T[t] = v;
 		WSYNC();
 		put_vec<Q>(s, d, to_svec<Q>(s.T[sl]), sl);
-	}
+	});
 	WSYNC();
 
 	auto emit = [&](double o, int d) {
@@ -536,35 +624,35 @@ __global__ __launch_bounds__(64) void cn_bp_small_kernel(NblGraphDev g, NblWork 
 }
 
 template <int Q> struct SmallLaunch {
-	static hipError_t tems(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
+	static constexpr int G = 64 / Q;
+	static dim3 grid(const NblGraphDev &g, const NblRun &r) { return dim3((unsigned)(((long long)r.B * g.M + G - 1) / G)); }
+	static hipError_t tems(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 	{
-		constexpr int G = 64 / Q;
 		const size_t lds = tems_small_group_bytes(Q, g.maxdc) * G;
-		const long long checks = (long long)r.B * g.M;
-		cn_tems_small_kernel<Q><<<dim3((unsigned)((checks + G - 1) / G)), dim3(64), lds, st>>>(g, w, r);
+		if (fused) cn_tems_small_kernel<Q, true><<<grid(g, r), dim3(64), lds, st>>>(g, w, r);
+		else cn_tems_small_kernel<Q, false><<<grid(g, r), dim3(64), lds, st>>>(g, w, r);
 		return hipGetLastError();
 	}
-	static hipError_t ems(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
+	static hipError_t ems(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 	{
-		constexpr int G = 64 / Q;
 		const int layers = nbl_ems_layers(g, r.nc);
 		const size_t lds = ems_small_group_bytes(Q, g.maxdc, r.nm, layers) * G;
-		const long long checks = (long long)r.B * g.M;
-		cn_ems_small_kernel<Q><<<dim3((unsigned)((checks + G - 1) / G)), dim3(64), lds, st>>>(g, w, r, layers);
+		if (fused) cn_ems_small_kernel<Q, true><<<grid(g, r), dim3(64), lds, st>>>(g, w, r, layers);
+		else cn_ems_small_kernel<Q, false><<<grid(g, r), dim3(64), lds, st>>>(g, w, r, layers);
 		return hipGetLastError();
 	}
-	static hipError_t bp(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st)
+	static hipError_t bp(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 	{
-		constexpr int G = 64 / Q;
 		const size_t lds = bp_small_group_bytes(Q, g.maxdc) * G;
-		const long long checks = (long long)r.B * g.M;
-		cn_bp_small_kernel<Q><<<dim3((unsigned)((checks + G - 1) / G)), dim3(64), lds, st>>>(g, w, r);
+		if (fused) cn_bp_small_kernel<Q, true><<<grid(g, r), dim3(64), lds, st>>>(g, w, r);
+		else cn_bp_small_kernel<Q, false><<<grid(g, r), dim3(64), lds, st>>>(g, w, r);
 		return hipGetLastError();
 	}
 };
 
 } // namespace
 
+// (fused launches additionally need g.c_nbr: variable degrees <= 3 -- nbl_api.cpp)
 // q <= 32, every check of degree >= 3 (the log-QSPA schedule below needs a middle edge), the LDS of a wave's 64 / q checks
 // within the 64 KB a launch gets without opting in; T-EMS: nc <= 3 and a path code of p * maxdc <= 32 bits as in the general kernel
 bool nbl_small_applicable(const NblGraphDev &g, int method, int min_dc, int nm, int nc)
@@ -579,13 +667,13 @@ bool nbl_small_applicable(const NblGraphDev &g, int method, int min_dc, int nm, 
 
 #define NBL_DISPATCH_SMALL(q, CALL)                    \
 	switch (q) {                                       \
-	case 4: return SmallLaunch<4>::CALL(g, w, r, st);  \
-	case 8: return SmallLaunch<8>::CALL(g, w, r, st);  \
-	case 16: return SmallLaunch<16>::CALL(g, w, r, st);\
-	case 32: return SmallLaunch<32>::CALL(g, w, r, st);\
+	case 4: return SmallLaunch<4>::CALL(g, w, r, fused, st);  \
+	case 8: return SmallLaunch<8>::CALL(g, w, r, fused, st);  \
+	case 16: return SmallLaunch<16>::CALL(g, w, r, fused, st);\
+	case 32: return SmallLaunch<32>::CALL(g, w, r, fused, st);\
 	default: return hipErrorInvalidValue;              \
 	}
 
-hipError_t nbl_launch_cn_ems_small(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st) { NBL_DISPATCH_SMALL(g.q, ems) }
-hipError_t nbl_launch_cn_tems_small(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st) { NBL_DISPATCH_SMALL(g.q, tems) }
-hipError_t nbl_launch_cn_bp_small(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st) { NBL_DISPATCH_SMALL(g.q, bp) }
+hipError_t nbl_launch_cn_ems_small(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st) { NBL_DISPATCH_SMALL(g.q, ems) }
+hipError_t nbl_launch_cn_tems_small(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st) { NBL_DISPATCH_SMALL(g.q, tems) }
+hipError_t nbl_launch_cn_bp_small(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st) { NBL_DISPATCH_SMALL(g.q, bp) }

@@ -26,6 +26,8 @@ struct NblGraphDev {
 	const int *c_h;     // [E] check-major edge coefficient
 	const int *c_hinv;  // [E] inverse coefficient
 	const uint8_t *mul; // [q*q] GF multiplication table (syndrome kernel)
+	const int *c_nbr;   // [E][4] q <= 32, variable degrees <= 3 only (else NULL): for check-major edge e of variable n the c2v slots of
+	                    // n's edges in order (third = -1 at degree 2) and, in [3], 1 if e is n's first edge (nbl_cn_small.hip, fused)
 	const unsigned long long *ems_toff; // [E][64] GF(256), all checks of degree 4 only (else NULL): for check-major edge e and lane l the
 	                    // byte offsets 8 * (h_e * a) of a = 2l, 2l+1, 128+2l, 129+2l, 16 bits each (nbl_cn_ems256.hip)
 };

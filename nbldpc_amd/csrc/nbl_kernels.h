@@ -25,9 +25,9 @@ hipError_t nbl_launch_cn_bp(const NblGraphDev &g, const NblWork &w, const NblRun
 
 // small fields (q <= 32), 64 / q checks per wave (nbl_cn_small.hip); method as in include/nbldpc.h (1 BP, 2 EMS, 4 T-EMS)
 bool nbl_small_applicable(const NblGraphDev &g, int method, int min_dc, int nm, int nc);
-hipError_t nbl_launch_cn_ems_small(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);
-hipError_t nbl_launch_cn_tems_small(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);
-hipError_t nbl_launch_cn_bp_small(const NblGraphDev &g, const NblWork &w, const NblRun &r, hipStream_t st);
+hipError_t nbl_launch_cn_ems_small(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st);
+hipError_t nbl_launch_cn_tems_small(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st);
+hipError_t nbl_launch_cn_bp_small(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st);
 
 // T-EMS check node for GF(64), check degree 4 (nbl_cn_tems64.hip)
 bool nbl_tems64_applicable(const NblGraphDev &g, bool all_dc4, int nr, int nc);

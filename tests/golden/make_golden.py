@@ -113,6 +113,13 @@ FER_SETS = {
                                      snr_begin=1.0, snr_step=0.5, snr_stop=2.0, constellation="BPSK", min_sim_cycle=48)),
     "cfg4_tems_bds": ("O2", dict(gfq=64, code=BDS, method=4, max_iter=50, parallel=4, tems_nr=2, tems_nc=3, nqam=64,
                                  constellation="GRAY_64QAM", random_msg=0, snr_begin=3.0, snr_stop=4.0, min_sim_cycle=28)),
+    # GF(16), check degrees 4 / 5 mixed: 2000-4000 frames per point through the waterfall (the small-field kernels' statistics)
+    "ems_gf16_u512_p8": ("O2", dict(gfq=16, code=U512_16, method=2, max_iter=20, parallel=8, ems_nm=8, ems_nc=3,
+                                    snr_begin=1.5, snr_step=0.5, snr_stop=2.5, constellation="BPSK", min_sim_cycle=2000)),
+    "tems_gf16_u256_p8": ("O2", dict(gfq=16, code=U256_16, method=4, max_iter=20, parallel=8, tems_nr=2, tems_nc=3,
+                                     snr_begin=1.5, snr_step=0.5, snr_stop=2.5, constellation="BPSK", min_sim_cycle=4000)),
+    "bp_gf16_u256_p8": ("O0", dict(gfq=16, code=U256_16, method=1, max_iter=20, parallel=8,
+                                   snr_begin=2.0, snr_step=0.5, snr_stop=3.0, constellation="BPSK", min_sim_cycle=2000)),
 }
 
 

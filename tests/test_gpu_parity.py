@@ -20,7 +20,6 @@ pytestmark = pytest.mark.gpu
 EMS_SETS = ["cfg2_ems_u128", "cfg3_ems_u512", "ems_nc2_shaped", "ems_nc1", "ems_gf16_dc5", "ems_gf16_nc4",
             "ems_gf16_u256_mixed", "ems_c256_qam"]
 TEMS_SETS = ["cfg4_tems_bds", "tems_gf16_dc5", "tems_gf16_u512_mixed", "tems_gf256_u256", "tems_c128_nr3"]
-IRREGULAR = ("tems_gf16_dc5", "tems_gf16_u512_mixed", "ems_gf16_u256_mixed")  # check degrees 4 and 5 mixed
 LLR_TOL = 1e-9
 
 
@@ -39,8 +38,6 @@ def _oracle_decoder(oracle, meta, max_iter, fixed=0):
 @pytest.mark.parametrize("generic", [0, 1, 2])
 @pytest.mark.parametrize("name", EMS_SETS + TEMS_SETS)
 def test_decisions_equal_reference(name, generic):
-    if generic == 2 and name in IRREGULAR:
-        pytest.skip("irregular GF(16) code: no specialised kernel, variants 1 and 2 are the same launch sequence")
     g, meta = load_golden(name)
     p, kw = meta["profile"], decoder_kwargs(meta["profile"])
     code = nb.Code(meta["code"])
@@ -57,8 +54,6 @@ def test_decisions_equal_reference(name, generic):
 @pytest.mark.parametrize("generic", [0, 1, 2])
 @pytest.mark.parametrize("name", EMS_SETS + TEMS_SETS)
 def test_state_bit_exact_vs_oracle_and_close_to_reference(oracle, name, generic):
-    if generic == 2 and name in IRREGULAR:
-        pytest.skip("irregular GF(16) code: no specialised kernel, variants 1 and 2 are the same launch sequence")
     g, meta = load_golden(name)
     p, kw = meta["profile"], decoder_kwargs(meta["profile"])
     code = nb.Code(meta["code"])
@@ -316,7 +311,7 @@ def _run_vs_oracle(oracle, codename, method, omethod, iters, L, kw, modes, exact
             r, o, it = od.decode(L[b])
             ref.append((r, o.copy(), it, [x.copy() for x in od.state()]))
         refs.append(ref)
-    for variant in (0, 1):  # 64 / q checks per wave (nbl_cn_small.hip); one check per wave (general kernels)
+    for variant in (0, 1, 2):  # 64 / q checks per wave (nbl_cn_small.hip), fused iteration; general kernels; small kernels, separate VN pass
         dec = nb.Decoder(code, method, iters, **kw)
         _force_generic(dec, variant)
         dec.record_state(True)
@@ -439,7 +434,7 @@ def test_field_sizes_without_a_shipped_code(oracle, q, method):
     for b in range(L.shape[0]):
         r, o, it = od.decode(L[b])
         ref.append((r, o.copy(), it, [x.copy() for x in od.state()]))
-    for variant in (0, 1):
+    for variant in (0, 1, 2):  # fused small-field iteration; general kernels; small-field check node behind the separate VN pass
         dec = nb.Decoder(code, meth, iters, **kw)
         _force_generic(dec, variant)
         dec.record_state(True)
@@ -846,8 +841,9 @@ def test_hipgraph_replay_of_the_iteration_loop(monkeypatch, name, fixed, poll):
 
 
 @pytest.mark.parametrize("code_name,cons,method,B,ebn0,iters,kw,rm,check_oracle", [
-    ("divsalar.UNBLDPC.128.64.GF.16", "BPSK", 4, 2500, 2.0, 20, dict(tems_nr=2, tems_nc=2), 1, True),     # general kernels
+    ("divsalar.UNBLDPC.128.64.GF.16", "BPSK", 4, 2500, 2.0, 20, dict(tems_nr=2, tems_nc=2), 1, True),     # small-field kernels
     ("divsalar.UNBLDPC.128.64.GF.16", "BPSK", 1, 1025, 2.0, 20, dict(), 1, True),
+    ("divsalar.UNBLDPC.256.128.GF.16", "BPSK", 2, 1500, 2.0, 20, dict(ems_nm=8, ems_nc=3), 1, True),      # check degrees 4 / 5 in one wave
     ("divsalar.UNBLDPC.128.64.GF.256", "BPSK", 2, 3000, 2.0, 50, dict(ems_nm=16, ems_nc=3), 1, False),     # fused EMS iteration
     ("BDS.576.288.GF.64", "GRAY_64QAM", 4, 2048, 3.0, 50, dict(tems_nr=2, tems_nc=3), 0, False),           # fused T-EMS iteration
 ])
