@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end rate of the harness (nbldpc_sim): link-chain front-end on the host + batched decode on the GPU + error count.
 
-usage: python tools/sim_throughput.py [cfg3|cfg2|cfg4] [parallel] [cycles] [ebn0]
+usage: python tools/sim_throughput.py [cfg3|cfg2|cfg4|cfg1|ems16|tems16] [parallel] [cycles] [ebn0]
 Runs the driver in a scratch directory for `cycles` simulation cycles (stop rule on the frame count only), prints its phase summary.
 NBL_DEVICE_DEMOD=0 builds the symbol LLRs on the host instead of shipping received samples; NBL_HOST_THREADS sets the front-end threads.
 """
@@ -17,6 +17,9 @@ from nbldpc_amd import hostlib  # noqa: E402
 CFG = {
     "cfg2": ("divsalar.UNBLDPC.128.64.GF.256", "BPSK", dict(gfq=256, method=2, max_iter=50, nqam=2, ems_nm=16, ems_nc=3)),
     "cfg3": ("divsalar.UNBLDPC.512.256.GF.256", "BPSK", dict(gfq=256, method=2, max_iter=50, nqam=2, ems_nm=32, ems_nc=3)),
+    "cfg1": ("divsalar.UNBLDPC.128.64.GF.16", "BPSK", dict(gfq=16, method=1, max_iter=20, nqam=2)),
+    "ems16": ("divsalar.UNBLDPC.512.256.GF.16", "BPSK", dict(gfq=16, method=2, max_iter=50, nqam=2, ems_nm=8, ems_nc=3)),
+    "tems16": ("divsalar.UNBLDPC.512.256.GF.16", "BPSK", dict(gfq=16, method=4, max_iter=50, nqam=2, tems_nr=2, tems_nc=3)),
     "cfg4": ("BDS.576.288.GF.64", "GRAY_64QAM", dict(gfq=64, method=4, max_iter=50, nqam=64, tems_nr=2, tems_nc=3, random_msg=0)),
 }
 
