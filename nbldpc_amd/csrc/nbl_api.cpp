@@ -142,11 +142,14 @@ static bool small_enabled()
 	return on;
 }
 
-// small fields (q <= 32): 64 / q checks per wave, any variable degree (nbl_cn_small.hip)
+// small fields (q <= 64): 64 / q checks per wave, any variable degree (nbl_cn_small.hip)
 static bool small_shape(const nbl_decoder *d)
 {
 	if (!small_enabled()) return false;
 	const nbl_params &p = d->prm;
+	// (GF(64), check degree 4, T-EMS has its own kernel: config 4)
+	if (p.method == NBL_METHOD_TEMS && d->all_dv2 && nbl_tems64_applicable(d->g, d->all_dc4, p.tems_nr, p.tems_nc)) return false;
+	if (p.method == NBL_METHOD_BP && nbl_bp64_applicable(d->g, d->all_dc4)) return false; // (and log-QSPA: nbl_cn_bp64.hip)
 	if (p.method == NBL_METHOD_EMS) return nbl_small_applicable(d->g, p.method, d->min_dc, p.ems_nm, p.ems_nc);
 	if (p.method == NBL_METHOD_TEMS) return nbl_small_applicable(d->g, p.method, d->min_dc, 0, p.tems_nc);
 	if (p.method == NBL_METHOD_BP) return nbl_small_applicable(d->g, p.method, d->min_dc, 0, 0);
@@ -160,7 +163,7 @@ static bool fused_shape(const nbl_decoder *d)
 	if (d->prm.method == NBL_METHOD_EMS) return nbl_ems256_applicable(d->g, d->all_dc4, d->prm.ems_nm, d->prm.ems_nc);
 	if (d->prm.method == NBL_METHOD_TEMS)
 		return nbl_tems64_applicable(d->g, d->all_dc4, d->prm.tems_nr, d->prm.tems_nc) || nbl_tems256_applicable(d->g, d->all_dc4, d->prm.tems_nr, d->prm.tems_nc);
-	if (d->prm.method == NBL_METHOD_BP) return nbl_bp256_applicable(d->g, d->all_dc4);
+	if (d->prm.method == NBL_METHOD_BP) return nbl_bp256_applicable(d->g, d->all_dc4) || nbl_bp64_applicable(d->g, d->all_dc4);
 	return false;
 }
 
@@ -328,7 +331,7 @@ extern "C" nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_m
 			}
 		if ((st = upload(d, toff, &d->g.ems_toff))) return fail_create(d, st, "");
 	}
-	if (q <= 32 && maxdv <= 3) {
+	if (q <= 64 && maxdv <= 3) {
 		// fused small-field iteration: everything the variable-node stage of a check-major edge needs, in one 16-byte row
 		std::vector<int> nbr((size_t)E * 4);
 		for (int ce = 0; ce < E; ce++) {
@@ -452,6 +455,7 @@ static nbl_status launch_cn(nbl_decoder *d, const NblRun &r, hipStream_t st)
 		break;
 	case NBL_METHOD_BP:
 		if (d->force_generic != 1 && nbl_bp256_applicable(d->g, d->all_dc4)) HIP_TRY(d, nbl_launch_cn_bp256(d->g, d->w, r, false, st));
+		else if (d->force_generic != 1 && nbl_bp64_applicable(d->g, d->all_dc4)) HIP_TRY(d, nbl_launch_cn_bp64(d->g, d->w, r, false, st));
 		else if (d->force_generic != 1 && small_on) HIP_TRY(d, nbl_launch_cn_bp_small(d->g, d->w, r, false, st));
 		else HIP_TRY(d, nbl_launch_cn_bp(d->g, d->w, r, st));
 		break;
@@ -497,13 +501,14 @@ static nbl_status enqueue_window(IterCtx &c, int it_lo, int it_hi, hipStream_t s
 			wf.c2v_prev = (it == 1 && c.zeros) ? c.zeros : (it & 1) ? c.bufA : c.bufB;
 			wf.c2v = (it & 1) ? c.bufB : c.bufA;
 			wf.store_v2c = d->record_state ? 1 : 0;
-			if (d->g.q <= 32) {
+			if (small_shape(d)) {
 				if (p.method == NBL_METHOD_EMS) HIP_TRY(d, nbl_launch_cn_ems_small(d->g, wf, c.r, true, st));
 				else if (p.method == NBL_METHOD_TEMS) HIP_TRY(d, nbl_launch_cn_tems_small(d->g, wf, c.r, true, st));
 				else HIP_TRY(d, nbl_launch_cn_bp_small(d->g, wf, c.r, true, st));
 			} else if (p.method == NBL_METHOD_EMS) HIP_TRY(d, nbl_launch_cn_ems256(d->g, wf, c.r, true, st));
 			else if (p.method == NBL_METHOD_TEMS && d->g.q == 64) HIP_TRY(d, nbl_launch_cn_tems64(d->g, wf, c.r, true, st));
 			else if (p.method == NBL_METHOD_TEMS) HIP_TRY(d, nbl_launch_cn_tems256(d->g, wf, c.r, true, st));
+			else if (d->g.q == 64) HIP_TRY(d, nbl_launch_cn_bp64(d->g, wf, c.r, true, st));
 			else HIP_TRY(d, nbl_launch_cn_bp256(d->g, wf, c.r, true, st));
 			HIP_TRY(d, mark(c, 2, st));
 			HIP_TRY(d, nbl_launch_syn(d->g, d->w, c.r, st));

@@ -1,0 +1,396 @@
+// nbldpc_amd/csrc/nbl_cn_bp64.hip -- exact log-domain QSPA check node for GF(64), check degree 4, variable degree 2 (the BDS
+// 576.288 code of BASELINE config 4, decoded with log-QSPA instead of T-EMS): NBLDPC.cpp:747-767, L_Back :1565, L_Forward :1593,
+// LLR_BoxPlus :1621-1712.
+//
+// The GF(256) kernel (nbl_cn_bp256.hip) re-laid for a field that fills a quarter of a wave: FOUR checks per wave, a group of 16
+// lanes per check, lane l of the group owns the four consecutive check-domain symbols 4l..4l+3 of every vector.  A 4x4 block of
+// the XOR convolution out[z] += A[x] B[z ^ x] (x = 4g..4g+3) needs four broadcast values of A and the four values of B at chunk
+// l ^ g: 16 FMAs per two 16-byte LDS gathers -- the one-symbol-per-lane kernels (nbl_cn_bp.hip, nbl_cn_small.hip) issue one
+// LDS read per FMA and are LDS-bound at q = 64.  Vectors are probabilities relative to their own maximum, mantissa x 2^e, in
+// registers; narrow convolutions (smaller range below 1000 nats) run on plain doubles pre-scaled by 2^500, wide ones scale
+// every term exactly against the output's top exponent; the two pairs of convolutions that share an operand run in one loop.
+// Groups are independent (own 2 KB of LDS, reductions on their own DPP row) and may diverge (narrow / wide, damping).
+//
+// Numerics as for the other log-QSPA kernels: hard decisions, flags and FER equal the reference's, LLRs within 1e-9 of the
+// oracle's FP64 restatement (the reference accumulates in 80-bit long double; SURVEY 8c hazard 3).
+#include <hip/hip_runtime.h>
+#include <climits>
+#include "nbl_device.h"
+#include "nbl_fastmath.h"
+#include "nbl_kernels.h"
+
+namespace {
+
+constexpr int Q = 64;    // field size
+constexpr int LPC = 16;  // lanes per check
+constexpr double LOG2E = 1.4426950408889634, LN2 = 0.6931471805599453;
+
+#define WSYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+
+// maximum over the 16 lanes of the group (one DPP row), delivered to every lane: xor 1, xor 2, mirror 8, mirror 16
+__device__ __forceinline__ int row_max_i32(int v)
+{
+	constexpr int ID = (int)0x80000000;
+	v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0xB1, 0xF, 0xF, false));
+	v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0x4E, 0xF, 0xF, false));
+	v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0x141, 0xF, 0xF, false));
+	v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0x140, 0xF, 0xF, false));
+	return v;
+}
+template <int CTRL> __device__ __forceinline__ double row_mov_f64(double x)
+{
+	const int lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), CTRL, 0xF, 0xF, false);
+	const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), CTRL, 0xF, 0xF, false);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_max_f64(double v)
+{
+	v = dmax(v, row_mov_f64<0xB1>(v));
+	v = dmax(v, row_mov_f64<0x4E>(v));
+	v = dmax(v, row_mov_f64<0x141>(v));
+	v = dmax(v, row_mov_f64<0x140>(v));
+	return v;
+}
+__device__ __forceinline__ unsigned row_ballot(bool p, int gi) { return (unsigned)(__ballot(p) >> (16 * gi)) & 0xffffu; }
+
+// DecideLLRVector (:1542-1562) for a vector held as v[i] = symbol l + 16 i: lowest symbol among the maxima of {0, v}
+__device__ __forceinline__ int row_decide(const double (&v)[4], int gi)
+{
+	const double mx = dmax(row_max_f64(dmax(dmax(v[0], v[1]), dmax(v[2], v[3]))), 0.0);
+	int arg = 0;
+#pragma unroll
+	for (int i = 3; i >= 0; i--) { // lowest slot first, then lowest lane
+		const unsigned hit = row_ballot(v[i] == mx, gi);
+		arg = hit ? 16 * i + __builtin_ctz(hit) : arg;
+	}
+	return mx > 0.0 ? arg : 0;
+}
+
+struct XVec {      // probabilities of the lane's four symbols relative to the vector's maximum
+	double m[4];   // mantissa in [1,2]
+	int e[4];      // exponent, <= 0 up to float rounding of the reference, clamped at -1e9
+	double mx;     // group-uniform: the (near-)maximum that was divided out (log domain)
+	double rng;    // group-uniform: upper bound of max - min (log domain)
+};
+
+__device__ __forceinline__ XVec to_xvec(const double (&L)[4])
+{
+	XVec r;
+	// reference and range on order-preserving 32-bit keys of the values rounded to float (nbl_cn_bp256.hip, to_xvec)
+	const int kx = nbl_key32(dmax(dmax(L[0], L[1]), dmax(L[2], L[3]))), kn = nbl_key32(dmin(dmin(L[0], L[1]), dmin(L[2], L[3])));
+	r.mx = (double)nbl_unkey32(row_max_i32(kx));
+	const double mn = (double)nbl_unkey32(-row_max_i32(-kn));
+	r.rng = (r.mx - mn) * (1.0 + 0x1p-20) + 0x1p-100;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		const double y = dmax((L[i] - r.mx) * LOG2E, -1.0e9);
+		const double f = floor(y);
+		r.m[i] = nbl_exp2_frac(y - f);
+		r.e[i] = (int)f;
+	}
+	return r;
+}
+
+struct Lds {
+	double2 *Am01, *Am23, *Bm01, *Bm23; // [16] operands: mantissas (or plain probabilities) of symbols (4c, 4c+1) / (4c+2, 4c+3)
+	int4 *Ae, *Be;                      // [16] exponents of symbols 4c..4c+3 (wide path); the second B operand of a pair (narrow)
+};
+
+// out[z] = LSE_x(A[x] + B[z^x]) - LSE_x(A[x] + B[x]) for the lane's symbols z = 4 l + i (log domain, out[0] = 0)
+__device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&out)[4], const Lds &s, int l, int gi)
+{
+	constexpr int SH = 500; // see lse_conv, nbl_cn_bp256.hip
+	double lse[4];
+	WSYNC();
+	if (fmin(A.rng, B.rng) < 1000.0) { // uniform inside the group
+		s.Am01[l] = make_double2(ldexp(A.m[0], A.e[0] + SH), ldexp(A.m[1], A.e[1] + SH));
+		s.Am23[l] = make_double2(ldexp(A.m[2], A.e[2] + SH), ldexp(A.m[3], A.e[3] + SH));
+		s.Bm01[l] = make_double2(ldexp(B.m[0], B.e[0] + SH), ldexp(B.m[1], B.e[1] + SH));
+		s.Bm23[l] = make_double2(ldexp(B.m[2], B.e[2] + SH), ldexp(B.m[3], B.e[3] + SH));
+		WSYNC();
+		double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+		for (int g = 0; g < LPC; g++) {
+			const double2 a01 = s.Am01[g], a23 = s.Am23[g];
+			const double2 b01 = s.Bm01[l ^ g], b23 = s.Bm23[l ^ g];
+			const double a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y};
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+#pragma unroll
+				for (int i = 0; i < 4; i++) acc[i] = __fma_rn(a[j], b[i ^ j], acc[i]);
+		}
+#pragma unroll
+		for (int i = 0; i < 4; i++) lse[i] = ((nbl_log_pos(acc[i]) - (2 * SH) * LN2) + A.mx) + B.mx;
+	} else {
+		s.Am01[l] = make_double2(A.m[0], A.m[1]);
+		s.Am23[l] = make_double2(A.m[2], A.m[3]);
+		s.Bm01[l] = make_double2(B.m[0], B.m[1]);
+		s.Bm23[l] = make_double2(B.m[2], B.m[3]);
+		s.Ae[l] = make_int4(A.e[0], A.e[1], A.e[2], A.e[3]);
+		s.Be[l] = make_int4(B.e[0], B.e[1], B.e[2], B.e[3]);
+		WSYNC();
+		// exact top exponent of every output (integer max-plus pass: 256 terms per output at q = 64), then every term scaled
+		// exactly against it -- far below the range gives 0, nothing is lost to underflow
+		int ex[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+#pragma unroll 2
+		for (int g = 0; g < LPC; g++) {
+			const int4 av = s.Ae[g], bv = s.Be[l ^ g];
+			const int ae[4] = {av.x, av.y, av.z, av.w}, be[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+#pragma unroll
+				for (int i = 0; i < 4; i++) ex[i] = max(ex[i], ae[j] + be[i ^ j]);
+		}
+		double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+		for (int g = 0; g < LPC; g++) {
+			const double2 a01 = s.Am01[g], a23 = s.Am23[g];
+			const double2 b01 = s.Bm01[l ^ g], b23 = s.Bm23[l ^ g];
+			const int4 av = s.Ae[g], bv = s.Be[l ^ g];
+			const double a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y};
+			const int ae[4] = {av.x, av.y, av.z, av.w}, be[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+#pragma unroll
+				for (int i = 0; i < 4; i++) acc[i] = __fma_rn(a[j], ldexp(b[i ^ j], ae[j] + be[i ^ j] - ex[i]), acc[i]);
+		}
+#pragma unroll
+		for (int i = 0; i < 4; i++) lse[i] = ((nbl_log_pos(acc[i]) + (double)ex[i] * LN2) + A.mx) + B.mx;
+	}
+	const double norm = __shfl(lse[0], 16 * gi, 64); // z = 0
+#pragma unroll
+	for (int i = 0; i < 4; i++) out[i] = lse[i] - norm;
+	if (l == 0) out[0] = 0.0;
+}
+
+// Two convolutions that share their first operand, A [+] B1 and A [+] B2, when both are narrow: one loop, the broadcast reads of
+// A serve both.  Returns false (nothing done) when either convolution is wide.
+__device__ __forceinline__ bool lse_conv_pair(const XVec &A, const XVec &B1, const XVec &B2, double (&out1)[4], double (&out2)[4], const Lds &s,
+                                              int l, int gi)
+{
+	constexpr int SH = 500;
+	if (!(fmin(A.rng, B1.rng) < 1000.0 && fmin(A.rng, B2.rng) < 1000.0)) return false; // uniform inside the group
+	double2 *const Cm01 = (double2 *)s.Ae, *const Cm23 = (double2 *)s.Be; // the exponent arrays are idle on the narrow path
+	WSYNC();
+	s.Am01[l] = make_double2(ldexp(A.m[0], A.e[0] + SH), ldexp(A.m[1], A.e[1] + SH));
+	s.Am23[l] = make_double2(ldexp(A.m[2], A.e[2] + SH), ldexp(A.m[3], A.e[3] + SH));
+	s.Bm01[l] = make_double2(ldexp(B1.m[0], B1.e[0] + SH), ldexp(B1.m[1], B1.e[1] + SH));
+	s.Bm23[l] = make_double2(ldexp(B1.m[2], B1.e[2] + SH), ldexp(B1.m[3], B1.e[3] + SH));
+	Cm01[l] = make_double2(ldexp(B2.m[0], B2.e[0] + SH), ldexp(B2.m[1], B2.e[1] + SH));
+	Cm23[l] = make_double2(ldexp(B2.m[2], B2.e[2] + SH), ldexp(B2.m[3], B2.e[3] + SH));
+	WSYNC();
+	double acc1[4] = {0.0, 0.0, 0.0, 0.0}, acc2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+	for (int g = 0; g < LPC; g++) {
+		const double2 a01 = s.Am01[g], a23 = s.Am23[g];
+		const double2 b01 = s.Bm01[l ^ g], b23 = s.Bm23[l ^ g];
+		const double2 c01 = Cm01[l ^ g], c23 = Cm23[l ^ g];
+		const double a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y}, c[4] = {c01.x, c01.y, c23.x, c23.y};
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				acc1[i] = __fma_rn(a[j], b[i ^ j], acc1[i]);
+				acc2[i] = __fma_rn(a[j], c[i ^ j], acc2[i]);
+			}
+	}
+	double l1[4], l2[4];
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		l1[i] = ((nbl_log_pos(acc1[i]) - (2 * SH) * LN2) + A.mx) + B1.mx;
+		l2[i] = ((nbl_log_pos(acc2[i]) - (2 * SH) * LN2) + A.mx) + B2.mx;
+	}
+	const double n1 = __shfl(l1[0], 16 * gi, 64), n2 = __shfl(l2[0], 16 * gi, 64);
+#pragma unroll
+	for (int i = 0; i < 4; i++) { out1[i] = l1[i] - n1; out2[i] = l2[i] - n2; }
+	if (l == 0) { out1[0] = 0.0; out2[0] = 0.0; }
+	return true;
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(64) void cn_bp_q64_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
+{
+	__shared__ __attribute__((aligned(16))) double smem[4][4 * Q]; // 2 KB per check: four permutation buffers, then operands + staging
+	const int lane = lane_id(), gi = lane >> 4, l = lane & 15;
+	const long long ci = (long long)blockIdx.x * 4 + gi;
+	int b = -1;
+	if (ci < (long long)r.B * g.M) {
+		b = nbl_codeword(w, r, (int)(ci / g.M));
+		if (b >= 0 && !r.fixed_iters && w.done[b]) b = -1;
+	}
+	if (b < 0) return; // (a whole group leaves; the others never look at its lanes)
+	const int m = (int)(ci % g.M), c0 = g.coff[m];
+	double *const sm = smem[gi];
+
+	double *V = w.v2c + (size_t)b * g.E * Q;
+	double *C = w.c2v + ((size_t)b * g.E + c0) * Q;
+
+	// inputs into the check domain: p_d[h_d a] = v2c_d[a], symbol 0 = LLR 0 (the A1 == 0 branch of LLR_BoxPlus, :1623-1632);
+	// the lane's variable-domain symbols are a = l + 16 i
+	int hsym[4][4];
+	if (!FUSED) {
+#pragma unroll
+		for (int d = 0; d < 4; d++) {
+			const double *Vd = V + (size_t)g.c_epos[c0 + d] * Q;
+			const uint8_t *mrow = g.mul + (size_t)g.c_h[c0 + d] * Q;
+			double in[4];
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				hsym[d][i] = mrow[l + 16 * i];
+				in[i] = (l + 16 * i == 0) ? 0.0 : Vd[l + 16 * i];
+			}
+#pragma unroll
+			for (int i = 0; i < 4; i++) sm[d * Q + hsym[d][i]] = in[i];
+		}
+	} else {
+		// FUSED: the variable-node pass of this iteration for the check's four edges (NBLDPC.cpp:676-691, :718-744): post = (L_ch +
+		// c2v_0) + c2v_1 of the edge's variable (dv = 2), hard decision by the check that holds the variable's first edge, v2c =
+		// post - c2v of this edge, damped 1/2 : 1/2 against the previous v2c when its hard decision moves.  The previous decision
+		// is what this stage recorded one iteration ago (w.edge_dec), so the previous v2c itself is loaded only in iteration 1
+		// (where it is L_ch) or when the decision moved.  Two edges at a time: their loads are issued before the first value is used.
+		const double *Cp = w.c2v_prev + (size_t)b * g.E * Q;
+#pragma unroll
+		for (int half = 0; half < 2; half++) {
+			double lch[2][4], ca[2][4], cb[2][4];
+			int nvar[2], eidx[2], before[2];
+			bool ownA[2];
+#pragma unroll
+			for (int u = 0; u < 2; u++) {
+				const int d = 2 * half + u;
+				const int n = g.c_var[c0 + d], e = g.c_epos[c0 + d], e0 = g.voff[n];
+				const double *pl = w.Lch + ((size_t)b * g.N + n) * Q;
+				const double *pa = Cp + (size_t)g.v_cpos[e0] * Q, *pb = Cp + (size_t)g.v_cpos[e0 + 1] * Q;
+				const uint8_t *mrow = g.mul + (size_t)g.c_h[c0 + d] * Q;
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					const int a = l + 16 * i;
+					hsym[d][i] = mrow[a];
+					lch[u][i] = pl[a];
+					ca[u][i] = pa[a];
+					cb[u][i] = pb[a];
+				}
+				nvar[u] = n;
+				eidx[u] = e;
+				ownA[u] = (e == e0);
+				before[u] = (r.iter > 1) ? w.edge_dec[(size_t)b * g.E + e] : 0;
+			}
+#pragma unroll
+			for (int u = 0; u < 2; u++) {
+				const int d = 2 * half + u;
+				double *Vd = V + (size_t)eidx[u] * Q;
+				double post[4], nv[4];
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					post[i] = (lch[u][i] + ca[u][i]) + cb[u][i];
+					nv[i] = post[i] - (ownA[u] ? ca[u][i] : cb[u][i]);
+				}
+				if (ownA[u]) {
+					const int dec = row_decide(post, gi);
+					if (l == 0) w.dec[(size_t)b * g.N + nvar[u]] = dec;
+					if (w.post) {
+#pragma unroll
+						for (int i = 0; i < 4; i++) w.post[((size_t)b * g.N + nvar[u]) * Q + l + 16 * i] = post[i];
+					}
+				}
+				int bf = before[u];
+				if (r.iter == 1) { // the previous v2c is L_ch (init kernel), nothing has been recorded yet
+					double ov[4];
+#pragma unroll
+					for (int i = 0; i < 4; i++) ov[i] = Vd[l + 16 * i];
+					bf = row_decide(ov, gi);
+				}
+				int after = row_decide(nv, gi);
+				if (bf != after) {
+#pragma unroll
+					for (int i = 0; i < 4; i++) nv[i] = __dadd_rn(__dmul_rn(r.damp_old, Vd[l + 16 * i]), __dmul_rn(r.damp_new, nv[i]));
+					if (l == 0) nv[0] = 0.0;
+					after = row_decide(nv, gi);
+				}
+				if (l == 0) w.edge_dec[(size_t)b * g.E + eidx[u]] = after;
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					const double x = (l + 16 * i == 0) ? 0.0 : nv[i];
+					Vd[l + 16 * i] = x;
+					sm[d * Q + hsym[d][i]] = x;
+				}
+			}
+		}
+	}
+	WSYNC();
+	XVec p[4];
+#pragma unroll
+	for (int d = 0; d < 4; d++) {
+		double L[4];
+#pragma unroll
+		for (int i = 0; i < 4; i++) L[i] = sm[d * Q + 4 * l + i];
+		p[d] = to_xvec(L);
+	}
+	WSYNC();
+
+	Lds s;
+	s.Am01 = (double2 *)sm;
+	s.Am23 = s.Am01 + LPC;
+	s.Bm01 = s.Am23 + LPC;
+	s.Bm23 = s.Bm01 + LPC;
+	s.Ae = (int4 *)(s.Bm23 + LPC);
+	s.Be = s.Ae + LPC;
+	double *T = (double *)(s.Be + LPC); // [Q] output staging (bytes 1536..2047 of the group's region)
+
+	auto emit = [&](const double (&o)[4], int d) {
+		WSYNC();
+#pragma unroll
+		for (int i = 0; i < 4; i++) T[4 * l + i] = o[i];
+		WSYNC();
+		double *Cd = C + (size_t)d * Q;
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int a = l + 16 * i;
+			Cd[a] = (a == 0) ? 0.0 : T[hsym[d][i]];
+		}
+	};
+
+	double o[4];
+	// forward: F2 = p0 [+] p1, F3 = F2 [+] p2 = output 3 (A2 == 0 case, :761-764); output 2 = F2 [+] p3
+	lse_conv(p[0], p[1], o, s, l, gi);
+	{
+		const XVec F2 = to_xvec(o);
+		double o2[4];
+		if (lse_conv_pair(F2, p[2], p[3], o, o2, s, l, gi)) {
+			emit(o, 3);
+			emit(o2, 2);
+		} else {
+			lse_conv(F2, p[2], o, s, l, gi);
+			emit(o, 3);
+			lse_conv(F2, p[3], o, s, l, gi);
+			emit(o, 2);
+		}
+	}
+	// backward: R1 = p3 [+] p2, R0 = R1 [+] p1 = output 0 (A1 == 0 case, :757-760); output 1 = p0 [+] R1 (taken as R1 [+] p0 in the
+	// paired loop: the same products, summed in the mirrored order)
+	lse_conv(p[3], p[2], o, s, l, gi);
+	{
+		const XVec R1 = to_xvec(o);
+		double o2[4];
+		if (lse_conv_pair(R1, p[1], p[0], o, o2, s, l, gi)) {
+			emit(o, 0);
+			emit(o2, 1);
+		} else {
+			lse_conv(R1, p[1], o, s, l, gi);
+			emit(o, 0);
+			lse_conv(p[0], R1, o, s, l, gi);
+			emit(o, 1);
+		}
+	}
+}
+
+} // namespace
+
+bool nbl_bp64_applicable(const NblGraphDev &g, bool all_dc4) { return g.q == 64 && all_dc4; }
+
+hipError_t nbl_launch_cn_bp64(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
+{
+	dim3 grid((unsigned)(((long long)r.B * g.M + 3) / 4)), block(64);
+	if (fused) cn_bp_q64_dc4_kernel<true><<<grid, block, 0, st>>>(g, w, r);
+	else cn_bp_q64_dc4_kernel<false><<<grid, block, 0, st>>>(g, w, r);
+	return hipGetLastError();
+}

@@ -1,5 +1,5 @@
-// nbldpc_amd/csrc/nbl_cn_small.hip -- check-node kernels for small fields (q <= 32: the three shipped GF(16) codes, BASELINE
-// config 1): EMS (NBLDPC.cpp:859-917), T-EMS (:1055-1130) and log-QSPA (:747-767).
+// nbldpc_amd/csrc/nbl_cn_small.hip -- check-node kernels for small fields (q <= 64: the three shipped GF(16) codes, BASELINE
+// config 1; q = 64 is the degenerate case of one check per wave, which still gets the fused iteration): EMS (NBLDPC.cpp:859-917), T-EMS (:1055-1130) and log-QSPA (:747-767).
 //
 // The general kernels (nbl_kernels.hip, nbl_cn_tems.hip, nbl_cn_bp.hip) give every check a whole wave, lane = symbol: at q = 16
 // three quarters of the lanes idle and every step of the (short, latency-bound) chain of LDS phases is paid per check.  Here a
@@ -35,6 +35,7 @@ template <int Q> __device__ __forceinline__ double gmax_f64(double v)
 	if (Q >= 8) v = dmax(v, dppx_f64<0x141>(v));  // row_half_mirror
 	if (Q >= 16) v = dmax(v, dppx_f64<0x140>(v)); // row_mirror
 	if (Q >= 32) v = dmax(v, __shfl_xor(v, 16, 64));
+	if (Q >= 64) v = dmax(v, __shfl_xor(v, 32, 64));
 	return v;
 }
 template <int Q> __device__ __forceinline__ int gmax_i32(int v)
@@ -45,13 +46,14 @@ template <int Q> __device__ __forceinline__ int gmax_i32(int v)
 	if (Q >= 8) v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0x141, 0xF, 0xF, false));
 	if (Q >= 16) v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0x140, 0xF, 0xF, false));
 	if (Q >= 32) v = max(v, __shfl_xor(v, 16, 64));
+	if (Q >= 64) v = max(v, __shfl_xor(v, 32, 64));
 	return v;
 }
 // the group's bits of a wave ballot, bit i = lane i of the group
-template <int Q> __device__ __forceinline__ unsigned gballot(bool p, int gi)
+template <int Q> __device__ __forceinline__ uint64_t gballot(bool p, int gi)
 {
 	const uint64_t m = __ballot(p);
-	return (unsigned)(m >> (gi * Q)) & ((Q == 32) ? 0xffffffffu : ((1u << (Q & 31)) - 1u));
+	return (Q == 64) ? m : (m >> (gi * (Q & 63))) & ((1ull << (Q & 63)) - 1ull);
 }
 
 // which (codeword, check) the lane's group works on
@@ -81,8 +83,8 @@ template <int Q> __device__ __forceinline__ Ctx<Q> ctx_init(const NblGraphDev &g
 template <int Q> __device__ __forceinline__ int gdecide(double v, int gi)
 {
 	const double mx = dmax(gmax_f64<Q>(v), 0.0);
-	const unsigned hit = gballot<Q>(v == mx, gi);
-	return (mx > 0.0 && hit) ? __builtin_ctz(hit) : 0;
+	const uint64_t hit = gballot<Q>(v == mx, gi);
+	return (mx > 0.0 && hit) ? __builtin_ctzll(hit) : 0;
 }
 
 // The dc incoming vectors of the group's check, handed to `stage(d, v)` edge by edge (v = the lane's symbol of v2c_d, 0 for
@@ -202,8 +204,8 @@ __global__ __launch_bounds__(64, 4) void cn_tems_small_kernel(NblGraphDev g, Nbl
 	for_each_input<Q, FUSED, true>(g, w, r, c, vin, [&](int d, double v) {
 		// most reliable symbol: strict '>' over ascending symbols from a running maximum of 0 (:1798-1807)
 		const double mx = dmax(gmax_f64<Q>(v), 0.0);
-		const unsigned hit = gballot<Q>(v == mx, c.gi);
-		const int arg = (mx > 0.0 && hit) ? __builtin_ctz(hit) : 0;
+		const uint64_t hit = gballot<Q>(v == mx, c.gi);
+		const int arg = (mx > 0.0 && hit) ? __builtin_ctzll(hit) : 0;
 		const uint8_t *mrow = g.mul + (size_t)g.c_h[c0 + d] * Q;
 		const int bd = mrow[arg]; // beta_d = h * argmax (0 if nothing positive)
 		betas |= (unsigned long long)bd << (8 * d);
@@ -240,12 +242,12 @@ __global__ __launch_bounds__(64, 4) void cn_tems_small_kernel(NblGraphDev g, Nbl
 	WSYNC();
 	for (int d = 0; d < dc; d++) {
 		// the deviation symbols of column d as a bit set of the group (every order gives the same minimum and the same path code)
-		unsigned cand = gballot<Q>((mask >> d) & 1, c.gi);
+		uint64_t cand = gballot<Q>((mask >> d) & 1, c.gi);
 		TState b = A[sl]; // q_d = 0: dU[d][0] = 0 (:1826), cost unchanged
 #pragma unroll
 		for (int l = 0; l < 4; l++) { b.v[l] = b.v[l] + 0.0; b.c[l] = b.c[l] * Q; }
 		while (cand) {
-			const int q = __builtin_ctz(cand);
+			const int q = __builtin_ctzll(cand);
 			cand &= cand - 1;
 			const double u = dU[d * Q + q];
 			const TState src = A[sl ^ q];
@@ -384,8 +386,9 @@ __global__ __launch_bounds__(64, 4) void cn_ems_small_kernel(NblGraphDev g, NblW
 				for (int k = sl; k < nm; k += Q) A[ls[j1 * nm + k].t] = 0.0 + ls[j1 * nm + k].v;
 			} else {
 				const int j1 = OTH(0), j2 = OTH(1);
+				const unsigned inv = ((1u << 20) + nm - 1) / nm; // idx / nm for idx < nm * nm <= 4096 without an integer division
 				for (int idx = sl; idx < nm * nm; idx += Q) {
-					const int k1 = idx / nm, k2 = idx - k1 * nm;
+					const int k1 = (int)(((unsigned)idx * inv) >> 20), k2 = idx - k1 * nm;
 					const EmsEnt e1 = ls[j1 * nm + k1], e2 = ls[j2 * nm + k2];
 					__hip_atomic_fetch_max(&A[e1.t ^ e2.t], (0.0 + e1.v) + e2.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
@@ -653,11 +656,13 @@ template <int Q> struct SmallLaunch {
 } // namespace
 
 // (fused launches additionally need g.c_nbr: variable degrees <= 3 -- nbl_api.cpp)
-// q <= 32, every check of degree >= 3 (the log-QSPA schedule below needs a middle edge), the LDS of a wave's 64 / q checks
+// q <= 64, every check of degree >= 3 (the log-QSPA schedule below needs a middle edge), the LDS of a wave's 64 / q checks
 // within the 64 KB a launch gets without opting in; T-EMS: nc <= 3 and a path code of p * maxdc <= 32 bits as in the general kernel
 bool nbl_small_applicable(const NblGraphDev &g, int method, int min_dc, int nm, int nc)
 {
-	if (g.q > 32 || g.q < 4 || min_dc < 3 || g.maxdc > NBL_MAXDC) return false;
+	// (q = 64, one check per wave: measured on the BDS code, B = 4096 -- log-QSPA gains 23 % from the fused iteration, EMS loses
+	//  11 % to the 64-step ranking loop; T-EMS not measured on an irregular GF(64) code, so it stays with the general kernel too)
+	if (g.q > (method == 1 ? 64 : 32) || g.q < 4 || min_dc < 3 || g.maxdc > NBL_MAXDC) return false;
 	const int G = 64 / g.q;
 	if (method == 2) return nbl_ems_layers(g, nc) <= 4 && ems_small_group_bytes(g.q, g.maxdc, nm, nbl_ems_layers(g, nc)) * G <= 64 * 1024;
 	if (method == 4) return nc <= 3 && g.p * g.maxdc <= 32 && tems_small_group_bytes(g.q, g.maxdc) * G <= 64 * 1024;
@@ -671,6 +676,7 @@ bool nbl_small_applicable(const NblGraphDev &g, int method, int min_dc, int nm, 
 	case 8: return SmallLaunch<8>::CALL(g, w, r, fused, st);  \
 	case 16: return SmallLaunch<16>::CALL(g, w, r, fused, st);\
 	case 32: return SmallLaunch<32>::CALL(g, w, r, fused, st);\
+	case 64: return SmallLaunch<64>::CALL(g, w, r, fused, st);\
 	default: return hipErrorInvalidValue;              \
 	}
 

@@ -41,6 +41,10 @@ hipError_t nbl_launch_cn_tems256(const NblGraphDev &g, const NblWork &w, const N
 bool nbl_bp256_applicable(const NblGraphDev &g, bool all_dc4);
 hipError_t nbl_launch_cn_bp256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st);
 
+// log-QSPA check node for GF(64), check degree 4: four checks per wave, four symbols per lane (nbl_cn_bp64.hip)
+bool nbl_bp64_applicable(const NblGraphDev &g, bool all_dc4);
+hipError_t nbl_launch_cn_bp64(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st);
+
 // AWGN channel + CRand on the device (nbl_noise.hip)
 hipError_t nbl_launch_noise_gen(const uint32_t *state, const uint32_t *jump, int L, int B, double *fn, uint32_t *flag_idx, double *flag_arg,
                                 unsigned *flag_count, unsigned cap, hipStream_t st);

@@ -330,7 +330,7 @@ def _run_vs_oracle(oracle, codename, method, omethod, iters, L, kw, modes, exact
 
 
 @pytest.mark.parametrize("nm,nc", [(4, 1), (8, 1), (8, 2), (8, 3), (8, 4), (16, 3), (5, 2), (12, 4)])
-@pytest.mark.parametrize("codename", SMALL_CODES)
+@pytest.mark.parametrize("codename", SMALL_CODES + ["BDS.576.288.GF.64"])
 def test_small_field_ems_every_shape_vs_oracle(oracle, codename, nm, nc):
     """GF(16), four checks per wave (nbl_cn_small.hip) and the general one-check-per-wave kernel beside it: message state after
     4 iterations bit-identical to the canonical oracle for every (nm, nc) -- plain convolution (nc >= dc - 1) and layered
@@ -355,7 +355,7 @@ def test_small_field_tems_every_shape_vs_oracle(oracle, codename, nr, nc):
                    [oracle.CANONICAL, oracle.LITERAL])
 
 
-@pytest.mark.parametrize("codename", SMALL_CODES)
+@pytest.mark.parametrize("codename", SMALL_CODES + ["BDS.576.288.GF.64"])
 def test_small_field_bp_vs_oracle(oracle, codename):
     """log-QSPA on GF(16): decisions, flags and iteration counts equal the oracle's FP64 restatement, LLR state within 1e-9, for
     ordinary frames, an all-zero frame and LLRs thousands of nats apart (the mantissa / exponent path).  No partially erased
@@ -407,15 +407,15 @@ def _random_code(q, seed, M=12, degs=(3, 4, 5, 6)):
 
 
 @pytest.mark.parametrize("method", ["ems", "ems_plain", "tems", "bp"])
-@pytest.mark.parametrize("q", [4, 8, 32, 128])
+@pytest.mark.parametrize("q", [4, 8, 32, 64, 128])
 def test_field_sizes_without_a_shipped_code(oracle, q, method):
     """GF(4), GF(8), GF(32) (16 / 8 / 2 checks per wave in nbl_cn_small.hip) and GF(128) (general kernels, two symbols per lane)
-    have no shipped code: synthetic irregular graphs (check degrees 3-6, variable degrees 2-3), every method, both kernel
+    have no shipped code, GF(64) has no irregular one: synthetic irregular graphs (check degrees 3-6, variable degrees 2-3), every method, both kernel
     families against the oracle -- EMS / T-EMS bit for bit on real-valued and on integer (tie-heavy) frames, log-QSPA within 1e-9.
     (log-QSPA runs 3 iterations here: these 12-check graphs are full of 4-cycles, and with LLRs hundreds of nats apart the
     box-plus is a max-plus sum, so from iteration 4 on a variable's own L_ch comes back with the opposite sign -- v2c entries that
     are zero up to rounding noise, whose sign then decides the damping (:730-741) differently in every implementation.)"""
-    code, edges = _random_code(q, 900 + q, degs=(3, 4, 5, 6) if q <= 32 else (3, 4))  # (T-EMS path code: p * maxdc <= 32 bits)
+    code, edges = _random_code(q, 900 + q, degs={64: (3, 4, 5), 128: (3, 4)}.get(q, (3, 4, 5, 6)))  # (T-EMS path code: p * maxdc <= 32 bits)
     N = code.N
     rng = np.random.default_rng(q)
     L = rng.normal(-1.5, 3, (5, N, q - 1))
@@ -426,7 +426,7 @@ def test_field_sizes_without_a_shipped_code(oracle, q, method):
         L[2] = rng.normal(-800, 600, (N, q - 1))
     meth, ometh, kw = {"ems": (nb.METHOD_EMS, oracle.EMS, dict(ems_nm=min(q, 6), ems_nc=2, ems_factor=1.1, ems_offset=0.1)),
                        "ems_plain": (nb.METHOD_EMS, oracle.EMS, dict(ems_nm=min(q, 5), ems_nc=5, ems_factor=1.0, ems_offset=0.0)),
-                       "tems": (nb.METHOD_TEMS, oracle.TEMS, dict(tems_nr=2, tems_nc=3 if q <= 32 else 2, tems_factor=1.0, tems_offset=0.0)),
+                       "tems": (nb.METHOD_TEMS, oracle.TEMS, dict(tems_nr=2, tems_nc=3 if q <= 64 else 2, tems_factor=1.0, tems_offset=0.0)),
                        "bp": (nb.METHOD_BP, oracle.BP, dict())}[method]
     iters = 3 if method == "bp" else 4
     od = oracle.Decoder(oracle.Code(edges=edges), oracle.GF(q), ometh, iters, oracle.CANONICAL, **kw)
