@@ -156,9 +156,15 @@ static bool small_shape(const nbl_decoder *d)
 	return false;
 }
 
+static bool ems64_shape(const nbl_decoder *d)
+{
+	return small_enabled() && d->prm.method == NBL_METHOD_EMS && nbl_ems64_applicable(d->g, d->min_dc, d->prm.ems_nm, d->prm.ems_nc);
+}
+
 static bool fused_shape(const nbl_decoder *d)
 {
-	if (small_shape(d)) return d->g.c_nbr != nullptr; // (variable degrees above 3: the small kernels behind the separate VN pass)
+	// (variable degrees above 3: these kernels behind the separate VN pass)
+	if (small_shape(d) || ems64_shape(d)) return d->g.c_nbr != nullptr;
 	if (!d->all_dv2) return false;
 	if (d->prm.method == NBL_METHOD_EMS) return nbl_ems256_applicable(d->g, d->all_dc4, d->prm.ems_nm, d->prm.ems_nc);
 	if (d->prm.method == NBL_METHOD_TEMS)
@@ -445,6 +451,7 @@ static nbl_status launch_cn(nbl_decoder *d, const NblRun &r, hipStream_t st)
 	case NBL_METHOD_EMS:
 		if (d->force_generic != 1 && nbl_ems256_applicable(d->g, d->all_dc4, r.nm, r.nc)) HIP_TRY(d, nbl_launch_cn_ems256(d->g, d->w, r, false, st));
 		else if (d->force_generic != 1 && small_on) HIP_TRY(d, nbl_launch_cn_ems_small(d->g, d->w, r, false, st));
+		else if (d->force_generic != 1 && ems64_shape(d)) HIP_TRY(d, nbl_launch_cn_ems64(d->g, d->w, r, false, st));
 		else HIP_TRY(d, nbl_launch_cn_ems(d->g, d->w, r, st));
 		break;
 	case NBL_METHOD_TEMS:
@@ -505,7 +512,8 @@ static nbl_status enqueue_window(IterCtx &c, int it_lo, int it_hi, hipStream_t s
 				if (p.method == NBL_METHOD_EMS) HIP_TRY(d, nbl_launch_cn_ems_small(d->g, wf, c.r, true, st));
 				else if (p.method == NBL_METHOD_TEMS) HIP_TRY(d, nbl_launch_cn_tems_small(d->g, wf, c.r, true, st));
 				else HIP_TRY(d, nbl_launch_cn_bp_small(d->g, wf, c.r, true, st));
-			} else if (p.method == NBL_METHOD_EMS) HIP_TRY(d, nbl_launch_cn_ems256(d->g, wf, c.r, true, st));
+			} else if (p.method == NBL_METHOD_EMS && d->g.q == 64) HIP_TRY(d, nbl_launch_cn_ems64(d->g, wf, c.r, true, st));
+			else if (p.method == NBL_METHOD_EMS) HIP_TRY(d, nbl_launch_cn_ems256(d->g, wf, c.r, true, st));
 			else if (p.method == NBL_METHOD_TEMS && d->g.q == 64) HIP_TRY(d, nbl_launch_cn_tems64(d->g, wf, c.r, true, st));
 			else if (p.method == NBL_METHOD_TEMS) HIP_TRY(d, nbl_launch_cn_tems256(d->g, wf, c.r, true, st));
 			else if (d->g.q == 64) HIP_TRY(d, nbl_launch_cn_bp64(d->g, wf, c.r, true, st));

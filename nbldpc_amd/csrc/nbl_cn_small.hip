@@ -1,5 +1,6 @@
-// nbldpc_amd/csrc/nbl_cn_small.hip -- check-node kernels for small fields (q <= 64: the three shipped GF(16) codes, BASELINE
-// config 1; q = 64 is the degenerate case of one check per wave, which still gets the fused iteration): EMS (NBLDPC.cpp:859-917), T-EMS (:1055-1130) and log-QSPA (:747-767).
+// nbldpc_amd/csrc/nbl_cn_small.hip -- check-node kernels for small fields (q <= 32: the three shipped GF(16) codes, BASELINE
+// config 1): EMS (NBLDPC.cpp:859-917), T-EMS (:1055-1130) and log-QSPA (:747-767).  (The templates also compile for q = 64, the
+// degenerate case of one check per wave; only log-QSPA uses that -- irregular GF(64) codes -- see nbl_small_applicable.)
 //
 // The general kernels (nbl_kernels.hip, nbl_cn_tems.hip, nbl_cn_bp.hip) give every check a whole wave, lane = symbol: at q = 16
 // three quarters of the lanes idle and every step of the (short, latency-bound) chain of LDS phases is paid per check.  Here a
@@ -374,10 +375,12 @@ __global__ __launch_bounds__(64, 4) void cn_ems_small_kernel(NblGraphDev g, NblW
 			S = dmax(S, acc);
 		}
 
-		// conf(nm,nc): at most nc edges deviate, each inside its nm best (:897)
+		// conf(nm,nc): at most nc edges deviate, each inside its nm best (:897); conf(nm,0) is the all-rank-0 configuration alone,
+		// which conf(q,1) already holds
 		double *A = A0, *Bq = B0;
 		WSYNC();
-		if (layers == 1) {
+		if (r.nc < 1) {
+		} else if (layers == 1) {
 			// nc >= dc-1: no deviation counting needed -> plain truncated max-plus convolution
 			A[sl] = NBL_NEG_INF;
 			WSYNC();

@@ -41,6 +41,10 @@ hipError_t nbl_launch_cn_tems256(const NblGraphDev &g, const NblWork &w, const N
 bool nbl_bp256_applicable(const NblGraphDev &g, bool all_dc4);
 hipError_t nbl_launch_cn_bp256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st);
 
+// EMS check node for GF(64): four checks per wave, four symbols per lane (nbl_cn_ems64.hip)
+bool nbl_ems64_applicable(const NblGraphDev &g, int min_dc, int nm, int nc);
+hipError_t nbl_launch_cn_ems64(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st);
+
 // log-QSPA check node for GF(64), check degree 4: four checks per wave, four symbols per lane (nbl_cn_bp64.hip)
 bool nbl_bp64_applicable(const NblGraphDev &g, bool all_dc4);
 hipError_t nbl_launch_cn_bp64(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st);

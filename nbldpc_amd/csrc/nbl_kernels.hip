@@ -444,8 +444,10 @@ __global__ __launch_bounds__(64) void cn_ems_kernel(NblGraphDev g, NblWork w, Nb
 		}
 
 		STAMP(3);
-		// conf(nm,nc): at most nc edges deviate, each inside its nm best (:897)
-		if (layers == 1) {
+		// conf(nm,nc): at most nc edges deviate, each inside its nm best (:897); conf(nm,0) is the all-rank-0 configuration alone,
+		// which conf(q,1) already holds
+		if (r.nc < 1) {
+		} else if (layers == 1) {
 			// nc >= dc-1: no deviation counting needed -> plain truncated max-plus convolution
 			double *A = s.A, *Bq = s.Bq;
 			__syncthreads();

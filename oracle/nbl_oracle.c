@@ -276,7 +276,7 @@ nblo_decoder *nblo_decoder_create(const nblo_code *code, const nblo_gf *gf, cons
 	d->srt_val = (double *)calloc((size_t)mdc * q, sizeof(double));
 	d->srt_sym = (int *)calloc((size_t)mdc * q, sizeof(int));
 	d->S = (double *)calloc(q, sizeof(double));
-	nc = prm->ems_nc > 0 ? prm->ems_nc : 0;
+	nc = prm->ems_nc > 1 ? prm->ems_nc : 1; /* (conf(q,1) runs the same DP with one deviation) */
 	d->dpA = (double *)calloc((size_t)(nc + 1) * q, sizeof(double));
 	d->dpB = (double *)calloc((size_t)(nc + 1) * q, sizeof(double));
 	d->dU = (double *)calloc((size_t)mdc * q, sizeof(double));

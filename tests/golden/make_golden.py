@@ -118,6 +118,11 @@ FER_SETS = {
                                     snr_begin=1.5, snr_step=0.5, snr_stop=2.5, constellation="BPSK", min_sim_cycle=2000)),
     "tems_gf16_u256_p8": ("O2", dict(gfq=16, code=U256_16, method=4, max_iter=20, parallel=8, tems_nr=2, tems_nc=3,
                                      snr_begin=1.5, snr_step=0.5, snr_stop=2.5, constellation="BPSK", min_sim_cycle=4000)),
+    # the BDS code with the two methods BASELINE config 4 does not use
+    "bp_bds_p4": ("O0", dict(gfq=64, code=BDS, method=1, max_iter=50, parallel=4, nqam=64, constellation="GRAY_64QAM", random_msg=0,
+                             snr_begin=1.5, snr_step=0.5, snr_stop=2.0, min_sim_cycle=120)),
+    "ems_bds_p4": ("O2", dict(gfq=64, code=BDS, method=2, max_iter=50, parallel=4, ems_nm=16, ems_nc=3, nqam=64, constellation="GRAY_64QAM",
+                              random_msg=0, snr_begin=1.5, snr_step=0.5, snr_stop=2.5, min_sim_cycle=200)),
     "bp_gf16_u256_p8": ("O0", dict(gfq=16, code=U256_16, method=1, max_iter=20, parallel=8,
                                    snr_begin=2.0, snr_step=0.5, snr_stop=3.0, constellation="BPSK", min_sim_cycle=2000)),
 }

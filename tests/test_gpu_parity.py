@@ -329,7 +329,7 @@ def _run_vs_oracle(oracle, codename, method, omethod, iters, L, kw, modes, exact
         dec.close()
 
 
-@pytest.mark.parametrize("nm,nc", [(4, 1), (8, 1), (8, 2), (8, 3), (8, 4), (16, 3), (5, 2), (12, 4)])
+@pytest.mark.parametrize("nm,nc", [(8, 0), (4, 1), (8, 1), (8, 2), (8, 3), (8, 4), (16, 3), (5, 2), (12, 4)])
 @pytest.mark.parametrize("codename", SMALL_CODES + ["BDS.576.288.GF.64"])
 def test_small_field_ems_every_shape_vs_oracle(oracle, codename, nm, nc):
     """GF(16), four checks per wave (nbl_cn_small.hip) and the general one-check-per-wave kernel beside it: message state after
