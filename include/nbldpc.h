@@ -78,7 +78,10 @@ typedef struct nbl_decoder nbl_decoder;
 
 /* gf_mul: q*q multiplication table, gf_inv: q inverses (gf_inv[0] ignored) -- the tables CGF::Initial loads
  * from ./SRC/Arith.Table.GF.<q>.txt (GF.cpp:81-113).  Addition must be XOR (checked against gf_mul's
- * distributivity is not attempted; the reference's tables are polynomial-basis for every q it ships). */
+ * distributivity is not attempted; the reference's tables are polynomial-basis for every q it ships).
+ * Shapes: q = 4 .. 256 (a power of two), check and variable degrees up to 8, ems_nm <= q, T-EMS with p * (largest check
+ * degree) <= 32 (q = 2^p; the path code of TEMS_ConstructConf in 32 bits); anything else is NBL_ERR_UNSUPPORTED / NBL_ERR_ARG
+ * with a message, at creation, never at the first decode. */
 nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_mul, const uint16_t *gf_inv,
                       const nbl_params *params, int device, nbl_decoder **out);
 void nbl_destroy(nbl_decoder *dec);
