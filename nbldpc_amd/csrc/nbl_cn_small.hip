@@ -316,13 +316,14 @@ __host__ __device__ inline size_t ems_small_group_bytes(int q, int mdc, int nm, 
 	return (n + 15) & ~(size_t)15;
 }
 
-template <int Q, bool FUSED>
+// NMT: ems_nm as a compile-time constant (8: the list loops unroll and their LDS reads are issued together) or 0 = run-time
+template <int Q, bool FUSED, int NMT>
 __global__ __launch_bounds__(64, 4) void cn_ems_small_kernel(NblGraphDev g, NblWork w, NblRun r, int layers)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const Ctx<Q> c = ctx_init<Q>(g, w, r);
 	if (!c.live) return;
-	const int sl = c.sl, dc = c.dc, c0 = c.c0, nm = r.nm, mdc = g.maxdc;
+	const int sl = c.sl, dc = c.dc, c0 = c.c0, nm = NMT ? NMT : r.nm, mdc = g.maxdc;
 	char *base = smem + (size_t)c.gi * ems_small_group_bytes(Q, mdc, nm, layers);
 	double *U = (double *)base;        // [mdc][Q]   check-domain input vectors: U[j][h_j*a] = v2c_j[a], U[j][0] = 0
 	double *A0 = U + mdc * Q;          // [layers][Q] DP ping
@@ -332,6 +333,15 @@ __global__ __launch_bounds__(64, 4) void cn_ems_small_kernel(NblGraphDev g, NblW
 	EmsEnt *ls = (EmsEnt *)(Sv + Q);   // [mdc][nm]  the nm most reliable entries of every edge, by rank (rank 0 first)
 
 	double *C = w.c2v + ((size_t)c.b * g.E + c0) * Q;
+	// list entries k0 .. nm-1: unrolled when nm is a compile-time constant
+	auto for_entries = [&](int k0, auto &&body) {
+		if constexpr (NMT > 0) {
+#pragma unroll
+			for (int k = k0; k < NMT; k++) body(k);
+		} else {
+			for (int k = k0; k < nm; k++) body(k);
+		}
+	};
 
 	// ---- stage the dc incoming vectors: permute into the check domain, rank, keep the nm best ---------------------------
 	for_each_input<Q, FUSED, false>(g, w, r, c, vin, [&](int j, double v) {
@@ -400,10 +410,10 @@ __global__ __launch_bounds__(64, 4) void cn_ems_small_kernel(NblGraphDev g, NblW
 			for (int l = 2; l < rn; l++) {
 				const int jl = OTH(l);
 				double acc = NBL_NEG_INF;
-				for (int k = 0; k < nm; k++) {
+				for_entries(0, [&](int k) {
 					const EmsEnt e = ls[jl * nm + k];
 					acc = dmax(acc, A[sl ^ e.t] + e.v);
-				}
+				});
 				if (l == rn - 1) S = dmax(S, acc);
 				else {
 					Bq[sl] = acc;
@@ -432,12 +442,12 @@ __global__ __launch_bounds__(64, 4) void cn_ems_small_kernel(NblGraphDev g, NblW
 				double acc[4];
 #pragma unroll
 				for (int d = 0; d < 4; d++) acc[d] = (d < layers) ? A[d * Q + (sl ^ top.t)] + top.v : NBL_NEG_INF;
-				for (int k = 1; k < nm; k++) {
+				for_entries(1, [&](int k) {
 					const EmsEnt e = ls[jl * nm + k];
 #pragma unroll
 					for (int d = 1; d < 4; d++)
 						if (d < layers && d <= l + 1) acc[d] = dmax(acc[d], A[(d - 1) * Q + (sl ^ e.t)] + e.v);
-				}
+				});
 				if (l == rn - 1) {
 #pragma unroll
 					for (int d = 0; d < 4; d++)
@@ -643,8 +653,13 @@ template <int Q> struct SmallLaunch {
 	{
 		const int layers = nbl_ems_layers(g, r.nc);
 		const size_t lds = ems_small_group_bytes(Q, g.maxdc, r.nm, layers) * G;
-		if (fused) cn_ems_small_kernel<Q, true><<<grid(g, r), dim3(64), lds, st>>>(g, w, r, layers);
-		else cn_ems_small_kernel<Q, false><<<grid(g, r), dim3(64), lds, st>>>(g, w, r, layers);
+		if (r.nm == 8 && Q >= 8) {
+			if (fused) cn_ems_small_kernel<Q, true, (Q >= 8 ? 8 : 0)><<<grid(g, r), dim3(64), lds, st>>>(g, w, r, layers);
+			else cn_ems_small_kernel<Q, false, (Q >= 8 ? 8 : 0)><<<grid(g, r), dim3(64), lds, st>>>(g, w, r, layers);
+		} else {
+			if (fused) cn_ems_small_kernel<Q, true, 0><<<grid(g, r), dim3(64), lds, st>>>(g, w, r, layers);
+			else cn_ems_small_kernel<Q, false, 0><<<grid(g, r), dim3(64), lds, st>>>(g, w, r, layers);
+		}
 		return hipGetLastError();
 	}
 	static hipError_t bp(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
