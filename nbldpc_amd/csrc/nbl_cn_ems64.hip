@@ -69,9 +69,9 @@ __device__ __forceinline__ double sym_value(const double (&v)[4], int a, int gi)
 struct Ent { double v; int t; }; // list entry: value, check-domain symbol (two arrays in LDS)
 
 // LDS per check -- what bounds the occupancy of this kernel (3.25 KB at dc = 4, nm = 16, plain convolution: three waves per SIMD):
-// the dc input vectors (which double as the staging of the incoming values), the DP buffers (one vector is enough for the plain
-// convolution over at most three other edges; it also stages the output), the lists as 8 + 4 bytes per entry
-__host__ __device__ inline int dp_vectors(int mdc, int layers) { return (layers == 1 && mdc <= 4) ? 1 : 2 * layers; }
+// the dc input vectors (which double as the staging of the incoming values), the DP layers (updated in place: every lane reads,
+// fence, every lane writes; they also stage the output), the lists as 8 + 4 bytes per entry
+__host__ __device__ inline int dp_vectors(int, int layers) { return layers; }
 __host__ __device__ inline size_t group_bytes(int mdc, int nm, int layers)
 {
 	return (((size_t)8 * ((size_t)mdc * Q + (size_t)dp_vectors(mdc, layers) * Q) + (size_t)12 * mdc * nm) + 15) & ~(size_t)15;
@@ -92,10 +92,9 @@ __global__ __launch_bounds__(64) void cn_ems_q64_kernel(NblGraphDev g, NblWork w
 	const int m = (int)(ci % g.M), c0 = g.coff[m], dc = g.coff[m + 1] - c0, nm = r.nm, mdc = g.maxdc;
 	char *base = smem + (size_t)gi * group_bytes(mdc, nm, layers);
 	double *U = (double *)base;              // [mdc][Q]   check-domain input vectors: U[j][h_j*a] = v2c_j[a], U[j][0] = 0
-	double *A0 = U + mdc * Q;                // [layers][Q] DP ping
-	double *B0 = A0 + layers * Q;            // [layers][Q] DP pong (absent when one vector is enough, see dp_vectors)
-	double *Sv = A0;                         // [Q]        the maxima of the current output edge (after its DP)
-	double *lv = A0 + dp_vectors(mdc, layers) * Q; // [mdc][nm] values of the nm most reliable entries of every edge (rank 0 first)
+	double *A = U + mdc * Q;                 // [layers][Q] DP layers
+	double *Sv = A;                          // [Q]        the maxima of the current output edge (after its DP)
+	double *lv = A + dp_vectors(mdc, layers) * Q; // [mdc][nm] values of the nm most reliable entries of every edge (rank 0 first)
 	int *lt = (int *)(lv + mdc * nm);        // [mdc][nm]  their check-domain symbols
 	auto entry = [&](int idx) {
 		Ent en;
@@ -260,7 +259,6 @@ __global__ __launch_bounds__(64) void cn_ems_q64_kernel(NblGraphDev g, NblWork w
 
 		// conf(nm,nc): at most nc edges deviate, each inside its nm best (:897); conf(nm,0) is the all-rank-0 configuration alone,
 		// which conf(q,1) already holds
-		double *A = A0, *Bq = B0;
 		WSYNC();
 		if (r.nc < 1) {
 		} else if (layers == 1) {
@@ -293,10 +291,10 @@ __global__ __launch_bounds__(64) void cn_ems_q64_kernel(NblGraphDev g, NblWork w
 #pragma unroll
 					for (int i = 0; i < 4; i++) S[i] = dmax(S[i], acc[i]);
 				} else {
-#pragma unroll
-					for (int i = 0; i < 4; i++) Bq[sl + 16 * i] = acc[i];
 					WSYNC();
-					double *T = A; A = Bq; Bq = T;
+#pragma unroll
+					for (int i = 0; i < 4; i++) A[sl + 16 * i] = acc[i];
+					WSYNC();
 				}
 			}
 			if (rn <= 2) {
@@ -344,14 +342,14 @@ __global__ __launch_bounds__(64) void cn_ems_q64_kernel(NblGraphDev g, NblWork w
 							for (int i = 0; i < 4; i++) S[i] = dmax(S[i], acc[d][i]);
 						}
 				} else {
+					WSYNC();
 #pragma unroll
 					for (int d = 0; d < 4; d++)
 						if (d < layers) {
 #pragma unroll
-							for (int i = 0; i < 4; i++) Bq[d * Q + sl + 16 * i] = acc[d][i];
+							for (int i = 0; i < 4; i++) A[d * Q + sl + 16 * i] = acc[d][i];
 						}
 					WSYNC();
-					double *T = A; A = Bq; Bq = T;
 				}
 			}
 			if (rn == 1)

@@ -99,36 +99,38 @@ template <int Q> __device__ __forceinline__ int gdecide(double v, int gi)
 // T-EMS 1/4 : 3/4 :1029-1052) the blend with the previous v2c when the message's hard decision moved.  The previous decision is
 // what this stage recorded one iteration ago (w.edge_dec), as in the GF(256) kernels; g.c_nbr holds the c2v slots of the
 // variable's edges, so the data loads are one index load deep.
-// The values of a chunk wait in `vin` ([4][Q] doubles of the group's LDS region), so the stage body exists once in the code.
-template <int Q, bool FUSED, bool DAMP, class Stage>
+// The values of a chunk wait in `vin` ([CH][Q] doubles of the group's LDS region), so the stage body exists once in the code.
+// CH trades loads in flight against registers (and registers against waves per SIMD: these kernels are latency-bound, their
+// throughput follows the occupancy).
+template <int Q, bool FUSED, bool DAMP, int CH, class Stage>
 __device__ __forceinline__ void for_each_input(const NblGraphDev &g, const NblWork &w, const NblRun &r, const Ctx<Q> &c, double *vin, Stage &&stage)
 {
 	const int sl = c.sl, dc = c.dc, c0 = c.c0;
-	for (int base = 0; base < dc; base += 4) {
+	for (int base = 0; base < dc; base += CH) {
 		if (!FUSED) {
 			const double *V = w.v2c + (size_t)c.b * g.E * Q;
-			double v[4];
+			double v[CH];
 #pragma unroll
-			for (int u = 0; u < 4; u++) {
+			for (int u = 0; u < CH; u++) {
 				const int d = (base + u < dc) ? base + u : 0;
 				v[u] = V[(size_t)g.c_epos[c0 + d] * Q + sl];
 			}
 #pragma unroll
-			for (int u = 0; u < 4; u++) vin[u * Q + sl] = (sl > 0) ? v[u] : 0.0;
+			for (int u = 0; u < CH; u++) vin[u * Q + sl] = (sl > 0) ? v[u] : 0.0;
 		} else {
 			const double *Cp = w.c2v_prev + (size_t)c.b * g.E * Q;
-			int4 row[4];
-			int n[4], e[4], before[4];
-			double L[4], x0[4], x1[4], x2[4], ov[4];
+			int4 row[CH];
+			int n[CH], e[CH], before[CH];
+			double L[CH], x0[CH], x1[CH], x2[CH], ov[CH];
 #pragma unroll
-			for (int u = 0; u < 4; u++) {
+			for (int u = 0; u < CH; u++) {
 				const int ce = c0 + ((base + u < dc) ? base + u : 0);
 				row[u] = ((const int4 *)g.c_nbr)[ce];
 				n[u] = g.c_var[ce];
 				e[u] = g.c_epos[ce];
 			}
 #pragma unroll
-			for (int u = 0; u < 4; u++) {
+			for (int u = 0; u < CH; u++) {
 				L[u] = w.Lch[((size_t)c.b * g.N + n[u]) * Q + sl];
 				x0[u] = Cp[(size_t)row[u].x * Q + sl];
 				x1[u] = Cp[(size_t)row[u].y * Q + sl];
@@ -139,7 +141,7 @@ __device__ __forceinline__ void for_each_input(const NblGraphDev &g, const NblWo
 				}
 			}
 #pragma unroll
-			for (int u = 0; u < 4; u++) {
+			for (int u = 0; u < CH; u++) {
 				if (base + u < dc) {
 					const int ce = c0 + base + u;
 					double post = (L[u] + x0[u]) + x1[u];
@@ -168,7 +170,7 @@ __device__ __forceinline__ void for_each_input(const NblGraphDev &g, const NblWo
 			}
 		}
 #pragma unroll 1
-		for (int u = 0; u < 4 && base + u < dc; u++) stage(base + u, vin[u * Q + sl]);
+		for (int u = 0; u < CH && base + u < dc; u++) stage(base + u, vin[u * Q + sl]);
 	}
 }
 
@@ -179,14 +181,14 @@ struct __attribute__((aligned(16))) TState { double v[4]; unsigned c[4]; };
 
 __host__ __device__ inline size_t tems_small_group_bytes(int q, int mdc)
 {
-	const size_t n = (size_t)8 * (mdc * q + q) + (size_t)2 * q * sizeof(TState);
+	const size_t n = (size_t)8 * (mdc * q + q) + (size_t)q * sizeof(TState);
 	return (n + 15) & ~(size_t)15;
 }
 
 template <int Q, bool FUSED>
-__global__ __launch_bounds__(64, 4) void cn_tems_small_kernel(NblGraphDev g, NblWork w, NblRun r)
+__global__ __launch_bounds__(64) void cn_tems_small_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
-	constexpr int P = Fld<Q>::P;
+	constexpr int P = Fld<Q>::P, TCH = 2; // (TState is 48 bytes per symbol: room for 6 staged vectors)
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const Ctx<Q> c = ctx_init<Q>(g, w, r);
 	if (!c.live) return;
@@ -194,15 +196,15 @@ __global__ __launch_bounds__(64, 4) void cn_tems_small_kernel(NblGraphDev g, Nbl
 	char *base = smem + (size_t)c.gi * tems_small_group_bytes(Q, mdc);
 	double *dU = (double *)base;                 // [mdc][Q]
 	double *Lc = dU + mdc * Q;                   // [Q]
-	TState *st = (TState *)(Lc + Q);             // [2][Q] DP states (ping-pong)
-	double *vin = (double *)st;                  // [4][Q] the incoming values of a chunk of edges (before the DP starts)
+	TState *A = (TState *)(Lc + Q);              // [Q] DP states, updated in place (every lane reads, fence, every lane writes)
+	double *vin = (double *)A;                   // [TCH][Q] the incoming values of a chunk of edges (before the DP starts)
 
 	double *C = w.c2v + ((size_t)c.b * g.E + c0) * Q;
 
 	// ---- 1. beta, syndrome, dU (TEMS_Get_Beta :1789-1812, TEMS_Get_deltaU :1814-1834) -------------------------------
 	int syn = 0;
 	unsigned long long betas = 0; // beta_d, 8 bits each (group-uniform)
-	for_each_input<Q, FUSED, true>(g, w, r, c, vin, [&](int d, double v) {
+	for_each_input<Q, FUSED, true, TCH>(g, w, r, c, vin, [&](int d, double v) {
 		// most reliable symbol: strict '>' over ascending symbols from a running maximum of 0 (:1798-1807)
 		const double mx = dmax(gmax_f64<Q>(v), 0.0);
 		const uint64_t hit = gballot<Q>(v == mx, c.gi);
@@ -232,7 +234,6 @@ __global__ __launch_bounds__(64, 4) void cn_tems_small_kernel(NblGraphDev g, Nbl
 	if (sl == 0) mask = 0; // symbol 0 = "no deviation" is handled apart
 
 	// ---- 3. min-plus DP over the columns; all deviation-count layers advance together (TEMS_ConstructConf :1892-1944) ----
-	TState *A = st, *Bs = st + Q;
 	{
 		TState z;
 #pragma unroll
@@ -266,9 +267,9 @@ __global__ __launch_bounds__(64, 4) void cn_tems_small_kernel(NblGraphDev g, Nbl
 				}
 			}
 		}
-		Bs[sl] = b;
 		WSYNC();
-		TState *tsw = A; A = Bs; Bs = tsw;
+		A[sl] = b;
+		WSYNC();
 	}
 	// dW, Eta: best layer per check sum
 	double dW = __builtin_huge_val();
@@ -311,14 +312,14 @@ struct __attribute__((aligned(16))) EmsEnt { double v; int t; int pad; }; // lis
 
 __host__ __device__ inline size_t ems_small_group_bytes(int q, int mdc, int nm, int layers)
 {
-	const size_t dp = 2 * (size_t)layers > 4 ? 2 * (size_t)layers : 4; // DP ping + pong; the staging of a chunk of inputs aliases them
+	const size_t dp = layers > 2 ? layers : 2; // DP layers (updated in place); the staging of a chunk of two inputs aliases them
 	const size_t n = (size_t)8 * ((size_t)mdc * q + (dp + 1) * q) + (size_t)16 * mdc * nm;
 	return (n + 15) & ~(size_t)15;
 }
 
 // NMT: ems_nm as a compile-time constant (8: the list loops unroll and their LDS reads are issued together) or 0 = run-time
 template <int Q, bool FUSED, int NMT>
-__global__ __launch_bounds__(64, 4) void cn_ems_small_kernel(NblGraphDev g, NblWork w, NblRun r, int layers)
+__global__ __launch_bounds__(64) void cn_ems_small_kernel(NblGraphDev g, NblWork w, NblRun r, int layers)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const Ctx<Q> c = ctx_init<Q>(g, w, r);
@@ -326,10 +327,9 @@ __global__ __launch_bounds__(64, 4) void cn_ems_small_kernel(NblGraphDev g, NblW
 	const int sl = c.sl, dc = c.dc, c0 = c.c0, nm = NMT ? NMT : r.nm, mdc = g.maxdc;
 	char *base = smem + (size_t)c.gi * ems_small_group_bytes(Q, mdc, nm, layers);
 	double *U = (double *)base;        // [mdc][Q]   check-domain input vectors: U[j][h_j*a] = v2c_j[a], U[j][0] = 0
-	double *A0 = U + mdc * Q;          // [layers][Q] DP ping
-	double *B0 = A0 + layers * Q;      // [layers][Q] DP pong
-	double *vin = A0;                  // [4][Q]     the incoming values of a chunk of edges (before the DP starts; >= 4 vectors there)
-	double *Sv = A0 + (2 * layers > 4 ? 2 * layers : 4) * Q; // [Q] variable-domain copy for the ranking, then the maxima of the current output edge
+	double *A = U + mdc * Q;           // [layers][Q] DP layers, updated in place (every lane reads, fence, every lane writes)
+	double *vin = A;                   // [2][Q]     the incoming values of a chunk of edges (before the DP starts; >= 2 vectors there)
+	double *Sv = A + (layers > 2 ? layers : 2) * Q; // [Q] variable-domain copy for the ranking, then the maxima of the current output edge
 	EmsEnt *ls = (EmsEnt *)(Sv + Q);   // [mdc][nm]  the nm most reliable entries of every edge, by rank (rank 0 first)
 
 	double *C = w.c2v + ((size_t)c.b * g.E + c0) * Q;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64, 4) void cn_ems_small_kernel(NblGraphDev g, NblW
 	};
 
 	// ---- stage the dc incoming vectors: permute into the check domain, rank, keep the nm best ---------------------------
-	for_each_input<Q, FUSED, false>(g, w, r, c, vin, [&](int j, double v) {
+	for_each_input<Q, FUSED, false, 2>(g, w, r, c, vin, [&](int j, double v) {
 		const int t = g.mul[(size_t)g.c_h[c0 + j] * Q + sl];
 		U[j * Q + t] = v;
 		WSYNC();
@@ -387,7 +387,6 @@ __global__ __launch_bounds__(64, 4) void cn_ems_small_kernel(NblGraphDev g, NblW
 
 		// conf(nm,nc): at most nc edges deviate, each inside its nm best (:897); conf(nm,0) is the all-rank-0 configuration alone,
 		// which conf(q,1) already holds
-		double *A = A0, *Bq = B0;
 		WSYNC();
 		if (r.nc < 1) {
 		} else if (layers == 1) {
@@ -416,9 +415,9 @@ __global__ __launch_bounds__(64, 4) void cn_ems_small_kernel(NblGraphDev g, NblW
 				});
 				if (l == rn - 1) S = dmax(S, acc);
 				else {
-					Bq[sl] = acc;
 					WSYNC();
-					double *T = A; A = Bq; Bq = T;
+					A[sl] = acc;
+					WSYNC();
 				}
 			}
 			if (rn <= 2) S = dmax(S, A[sl]);
@@ -453,11 +452,11 @@ __global__ __launch_bounds__(64, 4) void cn_ems_small_kernel(NblGraphDev g, NblW
 					for (int d = 0; d < 4; d++)
 						if (d < layers) S = dmax(S, acc[d]);
 				} else {
+					WSYNC();
 #pragma unroll
 					for (int d = 0; d < 4; d++)
-						if (d < layers) Bq[d * Q + sl] = acc[d];
+						if (d < layers) A[d * Q + sl] = acc[d];
 					WSYNC();
-					double *T = A; A = Bq; Bq = T;
 				}
 			}
 			if (rn == 1)
@@ -514,9 +513,11 @@ struct BpLds {
 	double *T;   // [Q] staging of an output vector
 };
 
+// vector slots of a check: p_0 .. p_mdc-1, then F_2 .. F_dc-2 (at least two slots: a chunk of two inputs is staged there)
+__host__ __device__ inline int bp_small_vectors(int mdc) { return mdc + (mdc - 3 > 2 ? mdc - 3 : 2); }
 __host__ __device__ inline size_t bp_small_group_bytes(int q, int mdc)
 {
-	const int nv = 2 * mdc;
+	const int nv = bp_small_vectors(mdc);
 	const size_t n = (size_t)nv * q * 12 + (size_t)nv * 16 + (size_t)q * 24 + (size_t)q * 8;
 	return (n + 15) & ~(size_t)15;
 }
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(64) void cn_bp_small_kernel(NblGraphDev g, NblWork 
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const Ctx<Q> c = ctx_init<Q>(g, w, r);
 	if (!c.live) return;
-	const int sl = c.sl, gi = c.gi, dc = c.dc, c0 = c.c0, mdc = g.maxdc, nv = 2 * mdc;
+	const int sl = c.sl, gi = c.gi, dc = c.dc, c0 = c.c0, mdc = g.maxdc, nv = bp_small_vectors(mdc);
 	char *base = smem + (size_t)gi * bp_small_group_bytes(Q, mdc);
 	BpLds s;
 	s.Vm = (double *)base;
@@ -588,15 +589,15 @@ __global__ __launch_bounds__(64) void cn_bp_small_kernel(NblGraphDev g, NblWork 
 	s.Pb = s.Pa + Q;
 	s.T = s.Pb + Q;
 	s.Ve = (int *)(s.T + Q);
-	double *vin = s.Vm + mdc * Q; // [min(4, mdc)][Q] the incoming values of a chunk of edges (the F slots are empty until all inputs are in)
+	double *vin = s.Vm + mdc * Q; // [2][Q] the incoming values of a chunk of edges (the F slots are empty until all inputs are in)
 	s.Ea = s.Ve + nv * Q;
 	s.Eb = s.Ea + Q;
 
 	double *C = w.c2v + ((size_t)c.b * g.E + c0) * Q;
 
 	// inputs into the check domain: p_d[h_d a] = v2c_d[a], symbol 0 = LLR 0 (the A1 == 0 branch of LLR_BoxPlus, :1623-1632);
-	// vector slots: p_d -> d, F_k (k = 2..dc-2) -> mdc + k - 2, the running R -> 2 mdc - 2 + (0 | 1)
-	for_each_input<Q, FUSED, true>(g, w, r, c, vin, [&](int d, double v) {
+	// vector slots: p_d -> d, F_k (k = 2..dc-2) -> mdc + k - 2 (the running R stays in registers)
+	for_each_input<Q, FUSED, true, 2>(g, w, r, c, vin, [&](int d, double v) {
 		const int t = g.mul[(size_t)g.c_h[c0 + d] * Q + sl];
 		WSYNC();
 		s.T[t] = v;
