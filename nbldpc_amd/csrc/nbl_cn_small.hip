@@ -186,7 +186,7 @@ __host__ __device__ inline size_t tems_small_group_bytes(int q, int mdc)
 }
 
 template <int Q, bool FUSED>
-__global__ __launch_bounds__(64) void cn_tems_small_kernel(NblGraphDev g, NblWork w, NblRun r)
+__global__ __launch_bounds__(64, 6) void cn_tems_small_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	constexpr int P = Fld<Q>::P, TCH = 2; // (TState is 48 bytes per symbol: room for 6 staged vectors)
 	extern __shared__ __attribute__((aligned(16))) char smem[];
