@@ -450,7 +450,9 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	// (a) a 256-bucket histogram of [lmin, mtop] (LDS atomics + DPP prefix sum) finds the bucket that holds the nm-th best
 	// value -- bucketing only has to be monotone, so its arithmetic needs no care; (b) a ballot quickselect, restricted to
 	// that bucket, finds the cut exactly; ties at the cut are resolved by symbol, higher first (:1731).
-	int n0[4] = {0, 0, 0, 0}; // entries with an even check-domain symbol per edge (they come first in the list)
+	// list layout per edge: the members of slot 0, of slot 2 (even symbols, bit 7 clear / set), of slot 1, of slot 3 (odd symbols);
+	// nA = end of the slot-0 run, n0 = end of the even symbols, nC = end of the slot-1 run
+	int n0[4] = {0, 0, 0, 0}, nA[4] = {0, 0, 0, 0}, nC[4] = {0, 0, 0, 0};
 	if (NC >= 2) { // conf(nm,1) needs no lists: it is contained in conf(q,1)
 		int bk[4][4];
 		int *H = (int *)B0; // [4 edges][256 buckets] (spans B0 and B1); lane l reads buckets 4l .. 4l+3 of every edge
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		// list entry fields of the lane's four slots: symbol and gather offset are the same for every edge
 		int2 tt2[4];
 #pragma unroll
-		for (int i = 0; i < 4; i++) { tt2[i].x = sym_of(lane, i) << 3; tt2[i].y = (sym_of(lane, i) & 0xFE) << 3; }
+		for (int i = 0; i < 4; i++) { tt2[i].x = sym_of(lane, i) << 3; tt2[i].y = (sym_of(lane, i) & 0x7E) << 3; }
 		// per edge: locate the cut bucket, settle the members, compact them into the list image
 		// [even-symbol group | odd-symbol group]
 #pragma unroll
@@ -522,6 +524,8 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			const int c0n = __popcll(member[0]), c2n = __popcll(member[2]), c1n = __popcll(member[1]);
 			const int ne = c0n + c2n;
 			n0[j] = ne;
+			nA[j] = c0n;
+			nC[j] = ne + c1n;
 			const int base[4] = {j * NM, j * NM + ne, j * NM + c0n, j * NM + ne + c1n};
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
@@ -599,16 +603,18 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		constexpr int NP = decltype(np_tag)::value;
 		constexpr int UN = 4; // entries per trip (twelve 16-byte gathers in flight in the three-way loop)
 		const char *Pb = (const char *)B0;
-		// entries [0, n0): even symbols, the lane's slot pairs line up; [n0, NM): odd symbols, the pairs are swapped.  UN entries
-		// per trip, then the remainder one by one (no padding entries: every trip is real work)
-		auto body = [&](const ListEnt &en, auto swapped) {
-			constexpr bool SW = decltype(swapped)::value;
-			const int ad = lane16 ^ en.tt, ad2 = ad ^ 1024;
+		// four runs of entries, by bit 0 and bit 7 of the entry's symbol t (both fixed by the slot the entry came from): bit 0 swaps
+		// the values inside a 16-byte slot (SW), bit 7 swaps the lower and the upper half of the vector (HI) -- as compile-time
+		// properties of the run neither costs an instruction, and the second gather address is the first plus 1024 (an offset
+		// field, no address arithmetic).  UN entries per trip, then the remainder one by one (no padding entries)
+		auto body = [&](const ListEnt &en, auto swapped, auto upper) {
+			constexpr bool SW = decltype(swapped)::value, HI = decltype(upper)::value;
+			const int ad = lane16 ^ en.tt; // (tt holds bits 1..6 of t only)
 			double2 ra[NP], rb[NP];
 #pragma unroll
 			for (int p = 0; p < NP; p++) {
-				ra[p] = *(const double2 *)(Pb + p * (Q * 8) + ad);
-				rb[p] = *(const double2 *)(Pb + p * (Q * 8) + ad2);
+				ra[p] = *(const double2 *)(Pb + p * (Q * 8) + ad + (HI ? 1024 : 0));
+				rb[p] = *(const double2 *)(Pb + p * (Q * 8) + ad + (HI ? 0 : 1024));
 			}
 #pragma unroll
 			for (int p = 0; p < NP; p++) {
@@ -629,19 +635,21 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			e.t8 = 0;
 			return e;
 		};
-		auto run = [&](int k0, int k1, auto swapped) {
+		auto run = [&](int k0, int k1, auto swapped, auto upper) {
 			int k = k0;
 			for (; k + UN <= k1; k += UN) {
 				ListEnt en[UN];
 #pragma unroll
 				for (int u = 0; u < UN; u++) en[u] = entry(k + u);
 #pragma unroll
-				for (int u = 0; u < UN; u++) body(en[u], swapped);
+				for (int u = 0; u < UN; u++) body(en[u], swapped, upper);
 			}
-			for (; k < k1; k++) body(entry(k), swapped);
+			for (; k < k1; k++) body(entry(k), swapped, upper);
 		};
-		run(0, n0[jc], std::false_type{});
-		run(n0[jc], NM, std::true_type{});
+		run(0, nA[jc], std::false_type{}, std::false_type{});
+		run(nA[jc], n0[jc], std::false_type{}, std::true_type{});
+		run(n0[jc], nC[jc], std::true_type{}, std::false_type{});
+		run(nC[jc], NM, std::true_type{}, std::true_type{});
 	};
 	// c2v[a] = shape(S[h_x a] - S[0]) (:899-916): the output goes back to the variable domain through LDS
 	auto emit_stage = [&](int x, double *Sx) {
