@@ -88,8 +88,8 @@ template <int Q> __device__ __forceinline__ int gdecide(double v, int gi)
 	return (mx > 0.0 && hit) ? __builtin_ctzll(hit) : 0;
 }
 
-// The dc incoming vectors of the group's check, handed to `stage(d, v)` edge by edge (v = the lane's symbol of v2c_d, 0 for
-// symbol 0).  FOUR EDGES AT A TIME: every global load of a chunk -- indices first, then data -- is issued before the first value
+// The dc incoming vectors of the group's check, handed to `stage(d, v, vec)` edge by edge (v = the lane's symbol of v2c_d, 0 for
+// symbol 0; vec = the whole vector in LDS, variable-domain order).  FOUR EDGES AT A TIME: every global load of a chunk -- indices first, then data -- is issued before the first value
 // is used, because the stage bodies are chains of LDS phases behind fences that no load can be hoisted over.
 //
 // FUSED (one launch = a whole flooding iteration, c2v double-buffered, variable degrees <= 3): the variable-node pass of a
@@ -170,7 +170,7 @@ __device__ __forceinline__ void for_each_input(const NblGraphDev &g, const NblWo
 			}
 		}
 #pragma unroll 1
-		for (int u = 0; u < CH && base + u < dc; u++) stage(base + u, vin[u * Q + sl]);
+		for (int u = 0; u < CH && base + u < dc; u++) stage(base + u, vin[u * Q + sl], vin + u * Q);
 	}
 }
 
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64, 6) void cn_tems_small_kernel(NblGraphDev g, Nbl
 	// ---- 1. beta, syndrome, dU (TEMS_Get_Beta :1789-1812, TEMS_Get_deltaU :1814-1834) -------------------------------
 	int syn = 0;
 	unsigned long long betas = 0; // beta_d, 8 bits each (group-uniform)
-	for_each_input<Q, FUSED, true, TCH>(g, w, r, c, vin, [&](int d, double v) {
+	for_each_input<Q, FUSED, true, TCH>(g, w, r, c, vin, [&](int d, double v, const double *) {
 		// most reliable symbol: strict '>' over ascending symbols from a running maximum of 0 (:1798-1807)
 		const double mx = dmax(gmax_f64<Q>(v), 0.0);
 		const uint64_t hit = gballot<Q>(v == mx, c.gi);
@@ -313,7 +313,7 @@ struct __attribute__((aligned(16))) EmsEnt { double v; int t; int pad; }; // lis
 __host__ __device__ inline size_t ems_small_group_bytes(int q, int mdc, int nm, int layers)
 {
 	const size_t dp = layers > 2 ? layers : 2; // DP layers (updated in place); the staging of a chunk of two inputs aliases them
-	const size_t n = (size_t)8 * ((size_t)mdc * q + (dp + 1) * q) + (size_t)16 * mdc * nm;
+	const size_t n = (size_t)8 * ((size_t)mdc * q + dp * q) + (size_t)16 * mdc * nm;
 	return (n + 15) & ~(size_t)15;
 }
 
@@ -329,8 +329,8 @@ __global__ __launch_bounds__(64) void cn_ems_small_kernel(NblGraphDev g, NblWork
 	double *U = (double *)base;        // [mdc][Q]   check-domain input vectors: U[j][h_j*a] = v2c_j[a], U[j][0] = 0
 	double *A = U + mdc * Q;           // [layers][Q] DP layers, updated in place (every lane reads, fence, every lane writes)
 	double *vin = A;                   // [2][Q]     the incoming values of a chunk of edges (before the DP starts; >= 2 vectors there)
-	double *Sv = A + (layers > 2 ? layers : 2) * Q; // [Q] variable-domain copy for the ranking, then the maxima of the current output edge
-	EmsEnt *ls = (EmsEnt *)(Sv + Q);   // [mdc][nm]  the nm most reliable entries of every edge, by rank (rank 0 first)
+	double *Sv = A;                    // [Q]        the maxima of the current output edge (after its DP)
+	EmsEnt *ls = (EmsEnt *)(A + (layers > 2 ? layers : 2) * Q); // [mdc][nm] the nm most reliable entries of every edge, by rank (rank 0 first)
 
 	double *C = w.c2v + ((size_t)c.b * g.E + c0) * Q;
 	// list entries k0 .. nm-1: unrolled when nm is a compile-time constant
@@ -344,17 +344,14 @@ __global__ __launch_bounds__(64) void cn_ems_small_kernel(NblGraphDev g, NblWork
 	};
 
 	// ---- stage the dc incoming vectors: permute into the check domain, rank, keep the nm best ---------------------------
-	for_each_input<Q, FUSED, false, 2>(g, w, r, c, vin, [&](int j, double v) {
+	for_each_input<Q, FUSED, false, 2>(g, w, r, c, vin, [&](int j, double v, const double *vec) {
 		const int t = g.mul[(size_t)g.c_h[c0 + j] * Q + sl];
 		U[j * Q + t] = v;
-		WSYNC();
-		Sv[sl] = v;
-		WSYNC();
 		// rank under SortLLRVector's order (:1715-1746): value descending, among equal values the HIGHER symbol first
 		int rank = 0;
 #pragma unroll 4
 		for (int x = 0; x < Q; x++) {
-			const double vo = Sv[x];
+			const double vo = vec[x];
 			rank += (vo > v || (vo == v && x > sl)) ? 1 : 0;
 		}
 		if (rank < nm) {
@@ -597,7 +594,7 @@ __global__ __launch_bounds__(64) void cn_bp_small_kernel(NblGraphDev g, NblWork 
 
 	// inputs into the check domain: p_d[h_d a] = v2c_d[a], symbol 0 = LLR 0 (the A1 == 0 branch of LLR_BoxPlus, :1623-1632);
 	// vector slots: p_d -> d, F_k (k = 2..dc-2) -> mdc + k - 2 (the running R stays in registers)
-	for_each_input<Q, FUSED, true, 2>(g, w, r, c, vin, [&](int d, double v) {
+	for_each_input<Q, FUSED, true, 2>(g, w, r, c, vin, [&](int d, double v, const double *) {
 		const int t = g.mul[(size_t)g.c_h[c0 + d] * Q + sl];
 		WSYNC();
 		s.T[t] = v;
