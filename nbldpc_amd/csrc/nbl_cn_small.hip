@@ -89,8 +89,9 @@ template <int Q> __device__ __forceinline__ int gdecide(double v, int gi)
 }
 
 // The dc incoming vectors of the group's check, handed to `stage(d, v, vec)` edge by edge (v = the lane's symbol of v2c_d, 0 for
-// symbol 0; vec = the whole vector in LDS, variable-domain order).  FOUR EDGES AT A TIME: every global load of a chunk -- indices first, then data -- is issued before the first value
-// is used, because the stage bodies are chains of LDS phases behind fences that no load can be hoisted over.
+// symbol 0; vec = the whole vector in LDS, variable-domain order).  CH EDGES AT A TIME: every global load of a chunk -- indices
+// first, then data -- is issued before the first value is used, because the stage bodies are chains of LDS phases behind
+// fences that no load can be hoisted over.
 //
 // FUSED (one launch = a whole flooding iteration, c2v double-buffered, variable degrees <= 3): the variable-node pass of a
 // check-major edge is recomputed from the previous iteration's c2v by the group that needs the message -- a-posteriori sum
@@ -169,6 +170,7 @@ __device__ __forceinline__ void for_each_input(const NblGraphDev &g, const NblWo
 				}
 			}
 		}
+		WSYNC(); // (the stages read other lanes' staged values)
 #pragma unroll 1
 		for (int u = 0; u < CH && base + u < dc; u++) stage(base + u, vin[u * Q + sl], vin + u * Q);
 	}
