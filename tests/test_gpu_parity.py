@@ -505,6 +505,10 @@ def test_bp_gf256_wide_ranges_and_exponent_fallback(oracle):
     (4, "BDS.576.288.GF.64", dict(tems_nr=2, tems_nc=3)),
     (1, "divsalar.UNBLDPC.128.64.GF.16", dict()),
     (1, "divsalar.CNBLDPC.512.256.GF.256", dict()),
+    (4, "divsalar.UNBLDPC.256.128.GF.16", dict(tems_nr=2, tems_nc=3)),   # four checks of different degree per wave
+    (2, "divsalar.UNBLDPC.256.128.GF.16", dict(ems_nm=8, ems_nc=3)),
+    (2, "BDS.576.288.GF.64", dict(ems_nm=16, ems_nc=3)),                 # four checks per wave, four symbols per lane
+    (1, "BDS.576.288.GF.64", dict()),
 ])
 def test_non_finite_inputs_terminate(method, codename, kw):
     """Garbage in (NaN, +-inf, 1e300) must not hang or fault any kernel: every data-dependent loop is bounded.  Outputs are
