@@ -241,7 +241,7 @@ def main():
         "roofline": {"kernel": "cn_ems_q256_dc4_kernel<32, fused>" if fused else "cn_ems_q256_dc4_kernel<32>", "bound": "hbm", "achieved": cn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": cn_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": PMC_SUMMARY + " (rocprofv3 --pmc passes of this command; not measured in this run)" if traffic else None,
                      "hbm_actual_GBps": (traffic / (cn_ms * 1e-3) / 1e9) if (traffic and cn_ms > 0) else None,
-                     "limiter": "fp64 valu issue + lds bandwidth (both ~75-80 % busy), not hbm",
+                     "limiter": "fp64 valu issue (~84 % busy) + lds port (~75 %), not hbm (profiles/r02_summary.json)",
                      "bytes_per_launch": cn_bytes_launch, "ms_per_launch": cn_ms},
     }
     if rank == 0 and world == 1 and args.cpu_sample != 0:
