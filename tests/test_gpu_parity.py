@@ -758,6 +758,17 @@ def test_other_methods_frame_by_frame_at_scale(tmp_path, oracle, name, code_name
     ("int_tems_u128", "divsalar.UNBLDPC.128.64.GF.256", "BPSK", 4, 1024, 2.0, 20, dict(tems_nr=2, tems_nc=3), 1),
     ("int_tems_u128_nc2", "divsalar.UNBLDPC.128.64.GF.256", "BPSK", 4, 1024, 2.0, 20, dict(tems_nr=3, tems_nc=2), 1),
     ("int_ems_u512", "divsalar.UNBLDPC.512.256.GF.256", "BPSK", 2, 1024, 1.0, 30, dict(ems_nm=32, ems_nc=3), 1),
+    # packed kernels: GF(16), four checks of degree 4 / 5 per wave; GF(64), four checks per wave with four symbols per lane
+    ("ems_u512_gf16", "divsalar.UNBLDPC.512.256.GF.16", "BPSK", 2, 4096, 1.8, 30, dict(ems_nm=8, ems_nc=3), 1),
+    ("ems_u256_gf16_nc2", "divsalar.UNBLDPC.256.128.GF.16", "BPSK", 2, 4096, 2.0, 30, dict(ems_nm=8, ems_nc=2, ems_factor=1.1, ems_offset=0.05), 1),
+    ("tems_u512_gf16", "divsalar.UNBLDPC.512.256.GF.16", "BPSK", 4, 4096, 1.8, 30, dict(tems_nr=2, tems_nc=3), 1),
+    ("bp_u256_gf16", "divsalar.UNBLDPC.256.128.GF.16", "BPSK", 1, 4096, 2.0, 20, dict(), 1),
+    ("int_ems_u512_gf16", "divsalar.UNBLDPC.512.256.GF.16", "BPSK", 2, 4096, 1.8, 30, dict(ems_nm=8, ems_nc=3), 1),
+    ("int_tems_u256_gf16", "divsalar.UNBLDPC.256.128.GF.16", "BPSK", 4, 4096, 2.0, 30, dict(tems_nr=2, tems_nc=3), 1),
+    ("ems_bds", "BDS.576.288.GF.64", "GRAY_64QAM", 2, 2048, 2.0, 50, dict(ems_nm=16, ems_nc=3), 0),
+    ("ems_bds_nc2", "BDS.576.288.GF.64", "GRAY_64QAM", 2, 1024, 2.0, 30, dict(ems_nm=16, ems_nc=2, ems_factor=1.1, ems_offset=0.05), 0),
+    ("int_ems_bds", "BDS.576.288.GF.64", "GRAY_64QAM", 2, 2048, 2.0, 30, dict(ems_nm=16, ems_nc=3), 0),
+    ("bp_bds", "BDS.576.288.GF.64", "GRAY_64QAM", 1, 1024, 1.8, 30, dict(), 0),
 ])
 def test_fused_specialised_and_general_kernels_agree_at_scale(tmp_path, label, code_name, cons, method, B, ebn0, iters, kw, rm):
     """Three independently written GPU paths -- fused iteration (one launch), specialised check node behind the separate VN
@@ -783,7 +794,10 @@ def test_fused_specialised_and_general_kernels_agree_at_scale(tmp_path, label, c
     o0, c0, i0 = res[0]
     assert 0.02 < c0.mean() < 0.999, c0.mean()  # converging and failing frames are both present
     if not label.startswith("int_"):
-        assert np.array_equal(o0[c0 == 1], tx[c0 == 1])
+        # a converged frame is the transmitted codeword -- except for the undetected errors of the small GF(16) codes (the
+        # reference's U-FER column: 1e-4 .. 1e-3 at these points, tests/golden/fer_anchors.json)
+        wrong = int(np.sum(np.any(o0[c0 == 1] != tx[c0 == 1], axis=1)))
+        assert wrong <= (B // 200 if q <= 16 else 0), (label, wrong)
     for o, c, i in res[1:]:
         assert np.array_equal(c, c0) and np.array_equal(i, i0), label
         if method == 1:
