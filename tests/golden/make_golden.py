@@ -126,6 +126,8 @@ FER_SETS = {
     # the CNBLDPC family over 256-QAM (all-zero codeword), EMS with the reference's sample-profile nc = 2
     "ems_c256_qam_p8": ("O2", dict(gfq=256, code=C256_256, method=2, max_iter=50, parallel=8, ems_nm=16, ems_nc=2, nqam=256,
                                    constellation="GRAY_256QAM", random_msg=0, snr_begin=4.0, snr_step=1.0, snr_stop=6.0, min_sim_cycle=200)),
+    "ems_c128_qam_p8": ("O2", dict(gfq=256, code=C128_256, method=2, max_iter=50, parallel=8, ems_nm=16, ems_nc=3, nqam=256,
+                                   constellation="GRAY_256QAM", random_msg=0, snr_begin=5.0, snr_step=1.0, snr_stop=7.0, min_sim_cycle=200)),
     "ems_u256_p8": ("O2", dict(gfq=256, code=U256_256, method=2, max_iter=50, parallel=8, ems_nm=32, ems_nc=3,
                                snr_begin=1.5, snr_step=0.5, snr_stop=2.0, constellation="BPSK", min_sim_cycle=120)),
     "bp_gf16_u256_p8": ("O0", dict(gfq=16, code=U256_16, method=1, max_iter=20, parallel=8,
