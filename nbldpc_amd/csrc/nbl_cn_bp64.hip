@@ -96,11 +96,14 @@ struct Lds {
 	int4 *Ae, *Be;                      // [16] exponents of symbols 4c..4c+3 (wide path); the second B operand of a pair (narrow)
 };
 
-// out[z] = LSE_x(A[x] + B[z^x]) - LSE_x(A[x] + B[x]) for the lane's symbols z = 4 l + i (log domain, out[0] = 0)
-__device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&out)[4], const Lds &s, int l, int gi)
+// The XOR convolution of two vectors for the lane's symbols z = 4 l + i: sum_x A[x] B[z^x] = acc[i] 2^ex[i] e^(A.mx + B.mx)
+struct ConvAcc { double acc[4]; int ex[4]; double base_a, base_b; };
+__device__ __forceinline__ ConvAcc conv_core(const XVec &A, const XVec &B, const Lds &s, int l)
 {
 	constexpr int SH = 500; // see lse_conv, nbl_cn_bp256.hip
-	double lse[4];
+	ConvAcc c;
+	c.base_a = A.mx;
+	c.base_b = B.mx;
 	WSYNC();
 	if (fmin(A.rng, B.rng) < 1000.0) { // uniform inside the group
 		s.Am01[l] = make_double2(ldexp(A.m[0], A.e[0] + SH), ldexp(A.m[1], A.e[1] + SH));
@@ -120,7 +123,7 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 				for (int i = 0; i < 4; i++) acc[i] = __fma_rn(a[j], b[i ^ j], acc[i]);
 		}
 #pragma unroll
-		for (int i = 0; i < 4; i++) lse[i] = ((nbl_log_pos(acc[i]) - (2 * SH) * LN2) + A.mx) + B.mx;
+		for (int i = 0; i < 4; i++) { c.acc[i] = acc[i]; c.ex[i] = -2 * SH; }
 	} else {
 		s.Am01[l] = make_double2(A.m[0], A.m[1]);
 		s.Am23[l] = make_double2(A.m[2], A.m[3]);
@@ -155,12 +158,49 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 				for (int i = 0; i < 4; i++) acc[i] = __fma_rn(a[j], ldexp(b[i ^ j], ae[j] + be[i ^ j] - ex[i]), acc[i]);
 		}
 #pragma unroll
-		for (int i = 0; i < 4; i++) lse[i] = ((nbl_log_pos(acc[i]) + (double)ex[i] * LN2) + A.mx) + B.mx;
+		for (int i = 0; i < 4; i++) { c.acc[i] = acc[i]; c.ex[i] = ex[i]; }
 	}
+	return c;
+}
+// ... as a message: out[z] = LSE_x(A[x] + B[z^x]) - LSE_x(A[x] + B[x]) (log domain, out[0] = 0)
+__device__ __forceinline__ void conv_log(const ConvAcc &c, double (&out)[4], int l, int gi)
+{
+	double lse[4];
+#pragma unroll
+	for (int i = 0; i < 4; i++) lse[i] = ((nbl_log_pos(c.acc[i]) + (double)c.ex[i] * LN2) + c.base_a) + c.base_b;
 	const double norm = __shfl(lse[0], 16 * gi, 64); // z = 0
 #pragma unroll
 	for (int i = 0; i < 4; i++) out[i] = lse[i] - norm;
 	if (l == 0) out[0] = 0.0;
+}
+// ... as the operand of the next convolution: the sums already are probabilities, so mantissa and exponent come from the value
+// itself (no logarithm per symbol, no exponential); reference = the power of two of the largest entry, whose log-domain level
+// relative to symbol 0 (= LLR 0, like every vector here) is E_max ln 2 - ln(sum of symbol 0)
+__device__ __forceinline__ XVec conv_xvec(const ConvAcc &c, int gi)
+{
+	XVec r;
+	int e[4], emax = INT_MIN, nemin = INT_MIN;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		int fe;
+		r.m[i] = 2.0 * frexp(c.acc[i], &fe); // acc = (m / 2) 2^fe
+		e[i] = fe - 1 + c.ex[i];
+		emax = max(emax, e[i]);
+		nemin = max(nemin, -e[i]);
+	}
+	emax = row_max_i32(emax);
+	nemin = row_max_i32(nemin);
+#pragma unroll
+	for (int i = 0; i < 4; i++) r.e[i] = e[i] - emax;
+	const double acc0 = __shfl(c.acc[0], 16 * gi, 64);
+	const int ex0 = __shfl(c.ex[0], 16 * gi, 64);
+	r.mx = (double)(emax - ex0) * LN2 - nbl_log_pos(acc0);
+	r.rng = (double)(emax + nemin + 1) * LN2;
+	return r;
+}
+__device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&out)[4], const Lds &s, int l, int gi)
+{
+	conv_log(conv_core(A, B, s, l), out, l, gi);
 }
 
 // Two convolutions that share their first operand, A [+] B1 and A [+] B2, when both are narrow: one loop, the broadcast reads of
@@ -351,9 +391,8 @@ __global__ __launch_bounds__(64) void cn_bp_q64_dc4_kernel(NblGraphDev g, NblWor
 
 	double o[4];
 	// forward: F2 = p0 [+] p1, F3 = F2 [+] p2 = output 3 (A2 == 0 case, :761-764); output 2 = F2 [+] p3
-	lse_conv(p[0], p[1], o, s, l, gi);
 	{
-		const XVec F2 = to_xvec(o);
+		const XVec F2 = conv_xvec(conv_core(p[0], p[1], s, l), gi);
 		double o2[4];
 		if (lse_conv_pair(F2, p[2], p[3], o, o2, s, l, gi)) {
 			emit(o, 3);
@@ -367,9 +406,8 @@ __global__ __launch_bounds__(64) void cn_bp_q64_dc4_kernel(NblGraphDev g, NblWor
 	}
 	// backward: R1 = p3 [+] p2, R0 = R1 [+] p1 = output 0 (A1 == 0 case, :757-760); output 1 = p0 [+] R1 (taken as R1 [+] p0 in the
 	// paired loop: the same products, summed in the mirrored order)
-	lse_conv(p[3], p[2], o, s, l, gi);
 	{
-		const XVec R1 = to_xvec(o);
+		const XVec R1 = conv_xvec(conv_core(p[3], p[2], s, l), gi);
 		double o2[4];
 		if (lse_conv_pair(R1, p[1], p[0], o, o2, s, l, gi)) {
 			emit(o, 0);
