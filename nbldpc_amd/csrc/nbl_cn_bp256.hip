@@ -85,9 +85,13 @@ struct Lds {
 	int4 *Ae, *Be;                      // [64] exponents of symbols 4c..4c+3
 };
 
-// out[z] = LSE_x(A[x] + B[z^x]) - LSE_x(A[x] + B[x]) for the lane's symbols z = 4 lane + i (log domain, out[0] = 0)
-__device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&out)[4], const Lds &s, int lane, unsigned long long *stamps)
+// The XOR convolution of two vectors for the lane's symbols z = 4 lane + i: sum_x A[x] B[z^x] = acc[i] 2^ex[i] e^(A.mx + B.mx)
+struct ConvAcc { double acc[4]; int ex[4]; double base_a, base_b; };
+__device__ __forceinline__ ConvAcc conv_core(const XVec &A, const XVec &B, const Lds &s, int lane, unsigned long long *stamps)
 {
+	ConvAcc c;
+	c.base_a = A.mx;
+	c.base_b = B.mx;
 	// Both operands are scaled by 2^500 for the plain-double path: an entry then survives down to e^-1054 of its vector's maximum
 	// and a product down to e^-1400 of the largest product.  Every output has a term >= e^-min(range) (the maximum of one vector
 	// times any entry of the other), and a term within e^-40 of it has both factors within e^-(min(range)+40) of their maxima:
@@ -98,7 +102,6 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 	// diagnostic build only (tools/bp_split.py): how many convolutions take the plain-double path / the mantissa-exponent path
 	if (stamps && lane == 0) atomicAdd(&stamps[narrow ? 0 : 1], 1ull);
 #endif
-	double lse[4];
 	if (narrow) {
 		s.Am01[lane] = make_double2(ldexp(A.m[0], A.e[0] + SH), ldexp(A.m[1], A.e[1] + SH));
 		s.Am23[lane] = make_double2(ldexp(A.m[2], A.e[2] + SH), ldexp(A.m[3], A.e[3] + SH));
@@ -117,7 +120,7 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 				for (int i = 0; i < 4; i++) acc[i] = __fma_rn(a[j], b[i ^ j], acc[i]);
 		}
 #pragma unroll
-		for (int i = 0; i < 4; i++) lse[i] = ((nbl_log_pos(acc[i]) - (2 * SH) * LN2) + A.mx) + B.mx;
+		for (int i = 0; i < 4; i++) { c.acc[i] = acc[i]; c.ex[i] = -2 * SH; }
 	} else {
 		s.Am01[lane] = make_double2(A.m[0], A.m[1]);
 		s.Am23[lane] = make_double2(A.m[2], A.m[3]);
@@ -179,13 +182,47 @@ __device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&
 			}
 		}
 #pragma unroll
-		for (int i = 0; i < 4; i++) lse[i] = ((nbl_log_pos(acc[i]) + (double)ex[i] * LN2) + A.mx) + B.mx;
+		for (int i = 0; i < 4; i++) { c.acc[i] = acc[i]; c.ex[i] = ex[i]; }
 	}
+	__syncthreads(); // operands are rewritten by the next convolution
+	return c;
+}
+// ... as a message: out[z] = LSE_x(A[x] + B[z^x]) - LSE_x(A[x] + B[x]) (log domain, out[0] = 0)
+__device__ __forceinline__ void lse_conv(const XVec &A, const XVec &B, double (&out)[4], const Lds &s, int lane, unsigned long long *stamps)
+{
+	const ConvAcc c = conv_core(A, B, s, lane, stamps);
+	double lse[4];
+#pragma unroll
+	for (int i = 0; i < 4; i++) lse[i] = ((nbl_log_pos(c.acc[i]) + (double)c.ex[i] * LN2) + c.base_a) + c.base_b;
 	const double norm = read_lane_f64(lse[0], 0); // z = 0
 #pragma unroll
 	for (int i = 0; i < 4; i++) out[i] = lse[i] - norm;
 	if (lane == 0) out[0] = 0.0;
-	__syncthreads(); // operands are rewritten by the next convolution
+}
+// ... as the operand of the next convolution: the sums already are probabilities, so mantissa and exponent come from the value
+// itself (no logarithm per symbol, no exponential); reference = the power of two of the largest entry, whose log-domain level
+// relative to symbol 0 (= LLR 0, like every vector here) is E_max ln 2 - ln(sum of symbol 0)
+__device__ __forceinline__ XVec conv_xvec(const ConvAcc &c)
+{
+	XVec r;
+	int e[4], emax = INT_MIN, nemin = INT_MIN;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		int fe;
+		r.m[i] = 2.0 * frexp(c.acc[i], &fe); // acc = (m / 2) 2^fe
+		e[i] = fe - 1 + c.ex[i];
+		emax = max(emax, e[i]);
+		nemin = max(nemin, -e[i]);
+	}
+	emax = wave_imax_id(emax);
+	nemin = wave_imax_id(nemin);
+#pragma unroll
+	for (int i = 0; i < 4; i++) r.e[i] = e[i] - emax;
+	const double acc0 = read_lane_f64(c.acc[0], 0);
+	const int ex0 = __builtin_amdgcn_readlane(c.ex[0], 0);
+	r.mx = (double)(emax - ex0) * LN2 - nbl_log_pos(acc0);
+	r.rng = (double)(emax + nemin + 1) * LN2;
+	return r;
 }
 
 // Two convolutions that share their first operand, A [+] B1 and A [+] B2, when both are narrow: one loop, the broadcast reads of
@@ -356,9 +393,8 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 
 	double o[4];
 	// forward: F2 = p0 [+] p1, F3 = F2 [+] p2 = output 3 (A2 == 0 case, :761-764); output 2 = F2 [+] p3
-	lse_conv(p[0], p[1], o, s, lane, w.stamps);
 	{
-		const XVec F2 = to_xvec(o, lane);
+		const XVec F2 = conv_xvec(conv_core(p[0], p[1], s, lane, w.stamps));
 		double o2[4];
 		if (lse_conv_pair(F2, p[2], p[3], o, o2, s, lane, w.stamps)) {
 			emit(o, 3);
@@ -371,9 +407,8 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 		}
 	}
 	// backward: R1 = p3 [+] p2, R0 = R1 [+] p1 = output 0 (A1 == 0 case, :757-760); output 1 = p0 [+] R1
-	lse_conv(p[3], p[2], o, s, lane, w.stamps);
 	{
-		const XVec R1 = to_xvec(o, lane);
+		const XVec R1 = conv_xvec(conv_core(p[3], p[2], s, lane, w.stamps));
 		double o2[4];
 		// output 1 = p0 [+] R1 is taken as R1 [+] p0 here: the same products, summed in the mirrored order
 		if (lse_conv_pair(R1, p[1], p[0], o, o2, s, lane, w.stamps)) {
