@@ -34,8 +34,9 @@ struct nbl_decoder {
 	int min_dc = 0;             // smallest check degree
 	bool all_dv2 = false;       // every variable has degree 2
 	double *c2v_alt = nullptr;  // second c2v buffer of the fused EMS iteration (flooding schedule -> double buffer)
-	double *c2v_zero = nullptr; // fused iterations: the all-zero c2v of iteration 0, written once when the workspace is made and only
-	                            // ever read (iteration 1 reads it instead of a buffer that would have to be cleared on every call)
+	double *c2v_zero = nullptr; // fused iterations: the all-zero c2v of iteration 0, ONE [E][q] block shared by all codewords, written once
+	                            // when the workspace is made and only ever read (iteration 1 reads it instead of a buffer that would
+	                            // have to be cleared on every call)
 	const double *last_c2v = nullptr;
 	bool last_fused = false;    // the last decode ran fused iterations (nbl_read_state picks the c2v buffer per codeword)
 	// device-side demodulator (nbl_set_demodulator)
@@ -61,7 +62,7 @@ struct nbl_decoder {
 	double *d_rxs[2] = {nullptr, nullptr}; // resident received samples of nbl_channel_batch, one per slot
 	size_t d_rxs_cap[2] = {0, 0};
 	int rxs_B[2] = {0, 0};
-	std::string err2;              // error text of the channel thread (nbl_last_error reports err first)
+	std::string err2;              // error text of the channel thread (nbl_channel_batch); nbl_last_error reports both
 	// hipGraph replay of the iteration loop: one executable graph per window of iterations (fixed iterations: the whole loop;
 	// early exit: the `poll_every` iterations between two polls), captured on the decoder's own stream the first time a window is
 	// run with a given set of buffers, replayed on the caller's stream afterwards.  NBL_GRAPH=0 switches it off.
@@ -82,14 +83,17 @@ struct nbl_decoder {
 	std::string err;
 };
 
-#define HIP_TRY(dec, call)                                                                         \
+// HIP_TRY_E: the failing call's text goes into `errstr` -- dec->err for everything the decode thread does, dec->err2 for the channel
+// thread (nbl_channel_batch may run beside a decode on the same handle, so the two never share a string)
+#define HIP_TRY_E(errstr, call)                                                                    \
 	do {                                                                                           \
 		hipError_t e_ = (call);                                                                    \
 		if (e_ != hipSuccess) {                                                                    \
-			(dec)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+			(errstr) = std::string(#call) + ": " + hipGetErrorString(e_);                          \
 			return NBL_ERR_HIP;                                                                    \
 		}                                                                                          \
 	} while (0)
+#define HIP_TRY(dec, call) HIP_TRY_E((dec)->err, call)
 
 static int ilog2(int q)
 {
@@ -189,8 +193,8 @@ static nbl_status ensure_workspace(nbl_decoder *d, int B)
 	HIP_TRY(d, alloc((void **)&d->w.c2v, (size_t)cap * E * q * 8));
 	if (fused_shape(d)) {
 		HIP_TRY(d, alloc((void **)&d->c2v_alt, (size_t)cap * E * q * 8));
-		HIP_TRY(d, alloc((void **)&d->c2v_zero, (size_t)cap * E * q * 8));
-		HIP_TRY(d, hipMemset(d->c2v_zero, 0, (size_t)cap * E * q * 8));
+		HIP_TRY(d, alloc((void **)&d->c2v_zero, E * q * 8)); // one block for every codeword (NblWork::c2v_prev_shared)
+		HIP_TRY(d, hipMemset(d->c2v_zero, 0, E * q * 8));
 	}
 	if (d->record_state) HIP_TRY(d, alloc((void **)&d->w.post, (size_t)cap * N * q * 8));
 	HIP_TRY(d, alloc((void **)&d->w.dec, (size_t)cap * N * 4));
@@ -206,7 +210,15 @@ static nbl_status ensure_workspace(nbl_decoder *d, int B)
 
 extern "C" int32_t nbl_abi_version(void) { return NBL_ABI_VERSION; }
 
-extern "C" const char *nbl_last_error(const nbl_decoder *dec) { return dec ? dec->err.c_str() : g_create_error.c_str(); }
+extern "C" const char *nbl_last_error(const nbl_decoder *dec)
+{
+	if (!dec) return g_create_error.c_str();
+	if (dec->err2.empty()) return dec->err.c_str();
+	if (dec->err.empty()) return dec->err2.c_str();
+	static thread_local std::string both;
+	both = dec->err + " | channel: " + dec->err2;
+	return both.c_str();
+}
 
 extern "C" size_t nbl_workspace_bytes(const nbl_decoder *dec) { return dec ? dec->ws_bytes : 0; }
 
@@ -224,7 +236,9 @@ extern "C" nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_m
 	*out = nullptr;
 	if (!code || !gf_mul || !gf_inv || !params) return fail_create(nullptr, NBL_ERR_ARG, "null argument");
 	const int N = code->N, M = code->M, q = code->q;
-	if (N <= 0 || M <= 0 || q < 4 || q > 256 || (q & (q - 1))) return fail_create(nullptr, NBL_ERR_ARG, "unsupported N/M/q (q must be 4..256, power of two)");
+	if (N <= 0 || M <= 0 || q < 4 || (q & (q - 1))) return fail_create(nullptr, NBL_ERR_ARG, "N, M must be positive and q a power of two, at least 4");
+	// (the reference ships arithmetic tables up to GF(512) but no code above GF(256); a valid request this library cannot serve)
+	if (q > 256) return fail_create(nullptr, NBL_ERR_UNSUPPORTED, "fields above GF(256) are not supported (one wave holds at most 4 symbols per lane)");
 	switch (params->method) {
 	case NBL_METHOD_EMS: case NBL_METHOD_BP: case NBL_METHOD_TEMS: break;
 	default: return fail_create(nullptr, NBL_ERR_UNSUPPORTED, "decode method not supported (reference: 'has not been developed' / OSD / BS-TEMS)");
@@ -337,8 +351,12 @@ extern "C" nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_m
 			}
 		if ((st = upload(d, toff, &d->g.ems_toff))) return fail_create(d, st, "");
 	}
-	if (q <= 64 && maxdv <= 3) {
+	int mindv = maxdv;
+	for (int n = 0; n < N; n++) mindv = code->var_deg[n] < mindv ? code->var_deg[n] : mindv;
+	if (q <= 64 && maxdv <= 3 && mindv >= 2) {
 		// fused small-field iteration: everything the variable-node stage of a check-major edge needs, in one 16-byte row
+		// (variable degrees 2 and 3 only: the fused loaders add the second c2v vector unconditionally; a code with a degree-1
+		// variable takes the separate variable-node launch, which handles any degree)
 		std::vector<int> nbr((size_t)E * 4);
 		for (int ce = 0; ce < E; ce++) {
 			const int n = c_var[ce], e0 = voff[n], dv = voff[n + 1] - e0;
@@ -412,6 +430,7 @@ extern "C" int32_t nbl_debug_graph_windows(nbl_decoder *d)
 extern "C" nbl_status nbl_debug_stamps(nbl_decoder *d, int32_t on, unsigned long long out[16])
 {
 	if (!d) return NBL_ERR_ARG;
+	d->err.clear();
 	HIP_TRY(d, hipSetDevice(d->device));
 	if (out && d->w.stamps) {
 		HIP_TRY(d, hipStreamSynchronize(d->stream));
@@ -506,6 +525,7 @@ static nbl_status enqueue_window(IterCtx &c, int it_lo, int it_hi, hipStream_t s
 			// one launch = variable-node pass + check-node pass; c2v ping-pongs between the two buffers
 			NblWork wf = d->w;
 			wf.c2v_prev = (it == 1 && c.zeros) ? c.zeros : (it & 1) ? c.bufA : c.bufB;
+			wf.c2v_prev_shared = (it == 1 && c.zeros) ? 1 : 0;
 			wf.c2v = (it & 1) ? c.bufB : c.bufA;
 			wf.store_v2c = d->record_state ? 1 : 0;
 			if (small_shape(d)) {
@@ -655,6 +675,7 @@ extern "C" nbl_status nbl_decode_batch_device(nbl_decoder *d, const double *d_L_
 {
 	if (!d || !d_L_ch || !d_out_sym || B < 0) return NBL_ERR_ARG;
 	if (B == 0) return NBL_OK;
+	d->err.clear();
 	HIP_TRY(d, hipSetDevice(d->device));
 	hipStream_t st = stream ? (hipStream_t)stream : d->stream;
 	nbl_status s = ensure_workspace(d, B);
@@ -671,6 +692,7 @@ extern "C" nbl_status nbl_decode_batch(nbl_decoder *d, const double *L_ch, int32
 {
 	if (!d || !L_ch || !out_sym || B < 0) return NBL_ERR_ARG;
 	if (B == 0) return NBL_OK;
+	d->err.clear();
 	HIP_TRY(d, hipSetDevice(d->device));
 	nbl_status s = ensure_workspace(d, B);
 	if (s) return s;
@@ -694,6 +716,7 @@ extern "C" nbl_status nbl_set_demodulator(nbl_decoder *d, const nbl_demod_desc *
 		return NBL_ERR_UNSUPPORTED;
 	}
 	if (dm->n_mod_sym <= 0 || (dm->mod_order == q && !dm->constellation)) return NBL_ERR_ARG;
+	d->err.clear();
 	HIP_TRY(d, hipSetDevice(d->device));
 	const size_t nsrc = dm->mod_order == 2 ? (size_t)N * p : (size_t)N;
 	for (size_t i = 0; i < nsrc; i++)
@@ -713,7 +736,10 @@ extern "C" nbl_status nbl_set_demodulator(nbl_decoder *d, const nbl_demod_desc *
 		HIP_TRY(d, hipMalloc((void **)&d->d_cons, (size_t)dm->mod_order * 16));
 		HIP_TRY(d, hipMemcpy(d->d_cons, dm->constellation, (size_t)dm->mod_order * 16, hipMemcpyHostToDevice));
 	}
+	// the channel's buffers are sized per lane of dm_L symbols and the jump table is per symbol position: both are rebuilt for
+	// the new L by the next channel call
 	if (d->d_jump) { (void)hipFree(d->d_jump); d->d_jump = nullptr; }
+	d->noise_cap = 0;
 	d->dm_order = dm->mod_order;
 	d->dm_L = dm->n_mod_sym;
 	return NBL_OK;
@@ -727,6 +753,7 @@ extern "C" nbl_status nbl_decode_batch_samples(nbl_decoder *d, const double *rx,
 	if (!d || !rx || !out_sym || B < 0 || !(sigma > 0)) return NBL_ERR_ARG;
 	if (!d->dm_order) { d->err = "nbl_set_demodulator has not been called"; return NBL_ERR_ARG; }
 	if (B == 0) return NBL_OK;
+	d->err.clear();
 	HIP_TRY(d, hipSetDevice(d->device));
 	nbl_status s = ensure_workspace(d, B);
 	if (s) return s;
@@ -767,7 +794,7 @@ extern "C" void nbl_rand_advance(uint32_t state[3], uint64_t draws)
 	state[2] = (uint32_t)((uint64_t)(state[2] % 63599u) * mod_pow(252, draws, 63599) % 63599u);
 }
 
-static nbl_status ensure_noise(nbl_decoder *d, int B)
+static nbl_status ensure_noise(nbl_decoder *d, int B, std::string &err)
 {
 	const size_t L = d->dm_L;
 	if (!d->d_jump) {
@@ -778,10 +805,10 @@ static nbl_status ensure_noise(nbl_decoder *d, int B)
 			const uint32_t a4 = mod_pow(A[g], 4, M[g]);
 			for (size_t s = 0; s < L; s++) { jump[g * L + s] = (uint32_t)x; x = x * a4 % M[g]; }
 		}
-		HIP_TRY(d, hipMalloc((void **)&d->d_jump, jump.size() * 4));
-		HIP_TRY(d, hipMemcpy(d->d_jump, jump.data(), jump.size() * 4, hipMemcpyHostToDevice));
+		HIP_TRY_E(err, hipMalloc((void **)&d->d_jump, jump.size() * 4));
+		HIP_TRY_E(err, hipMemcpy(d->d_jump, jump.data(), jump.size() * 4, hipMemcpyHostToDevice));
 	}
-	if ((size_t)B <= d->noise_cap) return NBL_OK;
+	if ((size_t)B <= d->noise_cap) return NBL_OK; // (capacity in lanes of dm_L symbols; nbl_set_demodulator resets it)
 	for (void *p : {(void *)d->d_state, (void *)d->d_txi, (void *)d->d_fn, (void *)d->d_fidx, (void *)d->d_farg, (void *)d->d_fval})
 		if (p) (void)hipFree(p);
 	for (void *p : {(void *)d->h_fidx, (void *)d->h_farg, (void *)d->h_fval})
@@ -790,18 +817,18 @@ static nbl_status ensure_noise(nbl_decoder *d, int B)
 	d->h_fidx = nullptr; d->h_farg = d->h_fval = nullptr;
 	d->noise_cap = 0;
 	const size_t nval = (size_t)B * L * 4; // two functions per normal draw, two draws per symbol
-	if (nval > 0xffffffffull) { d->err = "nbl_decode_batch_noise: batch * symbols too large for 32-bit value indices"; return NBL_ERR_ARG; }
+	if (nval > 0xffffffffull) { err = "nbl_decode_batch_noise: batch * symbols too large for 32-bit value indices"; return NBL_ERR_ARG; }
 	// about 16 % of the values are uncertain (5 % of the logarithms, 11 % of the cosines); room for 30 %
 	const size_t cap = nval * 3 / 10 + 4096;
-	HIP_TRY(d, hipMalloc((void **)&d->d_state, (size_t)B * 12));
-	HIP_TRY(d, hipMalloc((void **)&d->d_txi, (size_t)B * L));
-	HIP_TRY(d, hipMalloc((void **)&d->d_fn, nval * 8));
-	HIP_TRY(d, hipMalloc((void **)&d->d_fidx, cap * 4));
-	HIP_TRY(d, hipMalloc((void **)&d->d_farg, cap * 8));
-	HIP_TRY(d, hipMalloc((void **)&d->d_fval, cap * 8));
-	if (!d->d_fcount) HIP_TRY(d, hipMalloc((void **)&d->d_fcount, 16));
-	HIP_TRY(d, hipHostMalloc((void **)&d->h_farg, cap * 8, hipHostMallocDefault));
-	HIP_TRY(d, hipHostMalloc((void **)&d->h_fval, cap * 8, hipHostMallocDefault));
+	HIP_TRY_E(err, hipMalloc((void **)&d->d_state, (size_t)B * 12));
+	HIP_TRY_E(err, hipMalloc((void **)&d->d_txi, (size_t)B * L));
+	HIP_TRY_E(err, hipMalloc((void **)&d->d_fn, nval * 8));
+	HIP_TRY_E(err, hipMalloc((void **)&d->d_fidx, cap * 4));
+	HIP_TRY_E(err, hipMalloc((void **)&d->d_farg, cap * 8));
+	HIP_TRY_E(err, hipMalloc((void **)&d->d_fval, cap * 8));
+	if (!d->d_fcount) HIP_TRY_E(err, hipMalloc((void **)&d->d_fcount, 16));
+	HIP_TRY_E(err, hipHostMalloc((void **)&d->h_farg, cap * 8, hipHostMallocDefault));
+	HIP_TRY_E(err, hipHostMalloc((void **)&d->h_fval, cap * 8, hipHostMallocDefault));
 	d->noise_cap = B;
 	d->flag_cap = cap;
 	return NBL_OK;
@@ -810,37 +837,42 @@ static nbl_status ensure_noise(nbl_decoder *d, int B)
 // Forms RX = TX + noise for B lanes in *rx_buf (grown on demand) on stream `st`: the three kernels of nbl_noise.hip with the host's
 // libm in between.  Returns with the samples complete in HBM.
 static nbl_status run_channel(nbl_decoder *d, const uint8_t *tx_index, const uint32_t *lane_state, double sigma, int B, hipStream_t st,
-                              double **rx_buf, size_t *rx_cap)
+                              double **rx_buf, size_t *rx_cap, std::string &err)
 {
-	if (!d->dm_order) { d->err = "nbl_set_demodulator has not been called"; return NBL_ERR_ARG; }
-	if (d->h_cons.empty() || !d->d_cons) { d->err = "the channel needs the constellation points (nbl_demod_desc.constellation), also for BPSK"; return NBL_ERR_ARG; }
-	nbl_status s = ensure_noise(d, B);
+	if (!d->dm_order) { err = "nbl_set_demodulator has not been called"; return NBL_ERR_ARG; }
+	if (d->h_cons.empty() || !d->d_cons) { err = "the channel needs the constellation points (nbl_demod_desc.constellation), also for BPSK"; return NBL_ERR_ARG; }
+	nbl_status s = ensure_noise(d, B, err);
 	if (s) return s;
 	const size_t L = d->dm_L;
+	{ // an index beyond the constellation would read past d_cons in the finish kernel
+		unsigned worst = 0;
+		for (size_t i = 0, n = (size_t)B * L; i < n; i++) worst = tx_index[i] > worst ? tx_index[i] : worst;
+		if ((int)worst >= d->dm_order) { err = "tx_index holds a value >= mod_order"; return NBL_ERR_ARG; }
+	}
 	const size_t bytes = (size_t)B * L * 16;
 	if (bytes > *rx_cap) {
 		if (*rx_buf) (void)hipFree(*rx_buf);
 		*rx_buf = nullptr;
-		HIP_TRY(d, hipMalloc((void **)rx_buf, bytes));
+		HIP_TRY_E(err, hipMalloc((void **)rx_buf, bytes));
 		*rx_cap = bytes;
 	}
 	const bool timing = getenv("NBL_CHANNEL_TIMING") != nullptr;
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t0 = now();
 	double t1 = t0, t2 = t0, t3 = t0;
-	HIP_TRY(d, hipMemcpyAsync(d->d_state, lane_state, (size_t)B * 12, hipMemcpyHostToDevice, st));
-	HIP_TRY(d, hipMemcpyAsync(d->d_txi, tx_index, (size_t)B * L, hipMemcpyHostToDevice, st));
-	HIP_TRY(d, hipMemsetAsync(d->d_fcount, 0, 4, st));
-	HIP_TRY(d, nbl_launch_noise_gen(d->d_state, d->d_jump, (int)L, B, d->d_fn, d->d_fidx, d->d_farg, d->d_fcount, (unsigned)d->flag_cap, st));
+	HIP_TRY_E(err, hipMemcpyAsync(d->d_state, lane_state, (size_t)B * 12, hipMemcpyHostToDevice, st));
+	HIP_TRY_E(err, hipMemcpyAsync(d->d_txi, tx_index, (size_t)B * L, hipMemcpyHostToDevice, st));
+	HIP_TRY_E(err, hipMemsetAsync(d->d_fcount, 0, 4, st));
+	HIP_TRY_E(err, nbl_launch_noise_gen(d->d_state, d->d_jump, (int)L, B, d->d_fn, d->d_fidx, d->d_farg, d->d_fcount, (unsigned)d->flag_cap, st));
 	unsigned nflag = 0;
-	HIP_TRY(d, hipMemcpyAsync(&nflag, d->d_fcount, 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(d, hipStreamSynchronize(st));
-	if (nflag > d->flag_cap) { d->err = "nbl_decode_batch_noise: more uncertain values than the list holds (30 % of all)"; return NBL_ERR_NOMEM; }
+	HIP_TRY_E(err, hipMemcpyAsync(&nflag, d->d_fcount, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY_E(err, hipStreamSynchronize(st));
+	if (nflag > d->flag_cap) { err = "nbl_decode_batch_noise: more uncertain values than the list holds (30 % of all)"; return NBL_ERR_NOMEM; }
 	d->last_flag_frac = (double)nflag / ((double)B * L * 4);
 	t1 = now();
 	if (nflag) {
-		HIP_TRY(d, hipMemcpyAsync(d->h_farg, d->d_farg, (size_t)nflag * 8, hipMemcpyDeviceToHost, st));
-		HIP_TRY(d, hipStreamSynchronize(st));
+		HIP_TRY_E(err, hipMemcpyAsync(d->h_farg, d->d_farg, (size_t)nflag * 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY_E(err, hipStreamSynchronize(st));
 		t2 = now();
 		// the host's own libm decides the uncertain values: log(1 - u1) or cos(2 pi u2), Rand.cpp:35
 		int T = (int)std::thread::hardware_concurrency();
@@ -862,11 +894,11 @@ static nbl_status run_channel(nbl_decoder *d, const uint8_t *tx_index, const uin
 			for (auto &x : th) x.join();
 		}
 		t3 = now();
-		HIP_TRY(d, hipMemcpyAsync(d->d_fval, d->h_fval, (size_t)nflag * 8, hipMemcpyHostToDevice, st));
-		HIP_TRY(d, nbl_launch_noise_patch(d->d_fn, d->d_fidx, d->d_fval, nflag, st));
+		HIP_TRY_E(err, hipMemcpyAsync(d->d_fval, d->h_fval, (size_t)nflag * 8, hipMemcpyHostToDevice, st));
+		HIP_TRY_E(err, nbl_launch_noise_patch(d->d_fn, d->d_fidx, d->d_fval, nflag, st));
 	}
-	HIP_TRY(d, nbl_launch_noise_finish(d->d_fn, d->d_txi, d->d_cons, sigma, (int)L, B, *rx_buf, st));
-	HIP_TRY(d, hipStreamSynchronize(st));
+	HIP_TRY_E(err, nbl_launch_noise_finish(d->d_fn, d->d_txi, d->d_cons, sigma, (int)L, B, *rx_buf, st));
+	HIP_TRY_E(err, hipStreamSynchronize(st));
 	if (timing)
 		fprintf(stderr, "[channel] B=%d: generate %.2f ms, list to host %.2f ms, host libm (%u values) %.2f ms, patch + finish %.2f ms\n", B,
 		        (t1 - t0) * 1e3, (t2 - t1) * 1e3, nflag, (t3 - t2) * 1e3, (now() - t3) * 1e3);
@@ -878,10 +910,11 @@ extern "C" nbl_status nbl_decode_batch_noise(nbl_decoder *d, const uint8_t *tx_i
 {
 	if (!d || !tx_index || !lane_state || !out_sym || B < 0 || !(sigma > 0)) return NBL_ERR_ARG;
 	if (B == 0) return NBL_OK;
+	d->err.clear();
 	HIP_TRY(d, hipSetDevice(d->device));
 	nbl_status s = ensure_workspace(d, B);
 	if (s) return s;
-	if ((s = run_channel(d, tx_index, lane_state, sigma, B, d->stream, &d->d_rx, &d->d_rx_cap))) return s;
+	if ((s = run_channel(d, tx_index, lane_state, sigma, B, d->stream, &d->d_rx, &d->d_rx_cap, d->err))) return s;
 	HIP_TRY(d, nbl_launch_demod(d->d_rx, d->dm_L, sigma, d->dm_order, d->d_cons, d->d_src, d->g, d->w, B, d->stream));
 	if ((s = run_iterations(d, nullptr, B, d->stream))) return s;
 	HIP_TRY(d, hipMemcpyAsync(out_sym, d->w.out, (size_t)B * d->g.N * 4, hipMemcpyDeviceToHost, d->stream));
@@ -895,10 +928,11 @@ extern "C" nbl_status nbl_decode_batch_noise(nbl_decoder *d, const uint8_t *tx_i
 extern "C" nbl_status nbl_channel_batch(nbl_decoder *d, int32_t slot, const uint8_t *tx_index, const uint32_t *lane_state, double sigma, int32_t B)
 {
 	if (!d || !tx_index || !lane_state || B <= 0 || slot < 0 || slot > 1 || !(sigma > 0)) return NBL_ERR_ARG;
-	if (hipSetDevice(d->device) != hipSuccess) return NBL_ERR_HIP;
-	if (!d->stream2 && hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking) != hipSuccess) return NBL_ERR_HIP;
+	d->err2.clear();
+	HIP_TRY_E(d->err2, hipSetDevice(d->device));
+	if (!d->stream2) HIP_TRY_E(d->err2, hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
 	d->rxs_B[slot] = 0;
-	const nbl_status s = run_channel(d, tx_index, lane_state, sigma, B, d->stream2, &d->d_rxs[slot], &d->d_rxs_cap[slot]);
+	const nbl_status s = run_channel(d, tx_index, lane_state, sigma, B, d->stream2, &d->d_rxs[slot], &d->d_rxs_cap[slot], d->err2);
 	if (s == NBL_OK) d->rxs_B[slot] = B;
 	return s;
 }
@@ -907,6 +941,7 @@ extern "C" nbl_status nbl_decode_batch_resident(nbl_decoder *d, int32_t slot, do
 {
 	if (!d || !out_sym || B <= 0 || slot < 0 || slot > 1 || !(sigma > 0)) return NBL_ERR_ARG;
 	if (d->rxs_B[slot] != B) { d->err = "nbl_decode_batch_resident: slot does not hold the samples of a batch of this size (nbl_channel_batch first)"; return NBL_ERR_ARG; }
+	d->err.clear();
 	HIP_TRY(d, hipSetDevice(d->device));
 	nbl_status s = ensure_workspace(d, B);
 	if (s) return s;
@@ -925,8 +960,9 @@ extern "C" nbl_status nbl_debug_channel(nbl_decoder *d, const uint8_t *tx_index,
                                         double *rx_out, double *flag_frac)
 {
 	if (!d || !tx_index || !lane_state || !rx_out || B <= 0) return NBL_ERR_ARG;
+	d->err.clear();
 	HIP_TRY(d, hipSetDevice(d->device));
-	nbl_status s = run_channel(d, tx_index, lane_state, sigma, B, d->stream, &d->d_rx, &d->d_rx_cap);
+	nbl_status s = run_channel(d, tx_index, lane_state, sigma, B, d->stream, &d->d_rx, &d->d_rx_cap, d->err);
 	if (s) return s;
 	HIP_TRY(d, hipMemcpyAsync(rx_out, d->d_rx, (size_t)B * d->dm_L * 16, hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(d, hipStreamSynchronize(d->stream));
@@ -938,6 +974,7 @@ extern "C" nbl_status nbl_debug_channel(nbl_decoder *d, const uint8_t *tx_index,
 extern "C" nbl_status nbl_debug_read_lch(nbl_decoder *d, int32_t b, double *out)
 {
 	if (!d || !out || b < 0 || b >= d->last_B) return NBL_ERR_ARG;
+	d->err.clear();
 	HIP_TRY(d, hipSetDevice(d->device));
 	const int q = d->g.q, N = d->g.N;
 	double *tmp = nullptr;
@@ -952,6 +989,7 @@ extern "C" nbl_status nbl_debug_read_lch(nbl_decoder *d, int32_t b, double *out)
 extern "C" nbl_status nbl_read_state(nbl_decoder *d, int32_t b, double *post, double *v2c, double *c2v)
 {
 	if (!d || b < 0 || b >= d->last_B) return NBL_ERR_ARG;
+	d->err.clear();
 	HIP_TRY(d, hipSetDevice(d->device));
 	const int q = d->g.q, N = d->g.N, E = d->g.E;
 	double *tmp = nullptr;
@@ -982,7 +1020,7 @@ extern "C" nbl_status nbl_read_state(nbl_decoder *d, int32_t b, double *post, do
 			HIP_TRY(d, hipMemcpy(&done, d->w.done + b, 1, hipMemcpyDeviceToHost));
 			if (done) src = (it == 1 && d->c2v_zero) ? d->c2v_zero : ((it - 1) & 1) ? d->c2v_alt : d->w.c2v; // buffer written by iteration it-1 (it = 1: the zeros)
 		}
-		rc = grab(src + (size_t)b * E * q, d->d_e2c_map, E, c2v);
+		rc = grab(src == d->c2v_zero ? src : src + (size_t)b * E * q, d->d_e2c_map, E, c2v); // (the zeros are one shared block)
 	}
 	(void)hipFree(tmp);
 	return rc;

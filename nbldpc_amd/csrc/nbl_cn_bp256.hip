@@ -278,8 +278,8 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 {
 	__shared__ __attribute__((aligned(16))) double smem[4 * Q]; // 8 KB: four permutation buffers, then the operands
 	const int lane = lane_id();
-	const int bid = blockIdx.x;
-	const int b = nbl_codeword(w, r, bid / g.M), m = bid % g.M;
+	const NblXcdSlot xs = nbl_xcd_slot(g.M); // all checks of a codeword on one XCD (nbl_device.h)
+	const int b = nbl_codeword(w, r, xs.slot), m = xs.unit;
 	if (b < 0) return;
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m];
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 			// FUSED: the variable-node pass of this iteration for this edge (NBLDPC.cpp:676-691, :718-744): post = (L_ch + c2v_0)
 			// + c2v_1 of the edge's variable (dv = 2), hard decision by the check that holds the variable's first edge,
 			// v2c = post - c2v of this edge, damped 1/2 : 1/2 against the previous v2c when its hard decision moves.
-			const double *Cp = w.c2v_prev + (size_t)b * g.E * Q;
+			const double *Cp = w.c2v_prev + (w.c2v_prev_shared ? (size_t)0 : (size_t)b * g.E * Q); // (iteration 1: one shared block of zeros)
 			const int n = g.c_var[c0 + d], e = g.c_epos[c0 + d], e0 = g.voff[n];
 			const double *pl = w.Lch + ((size_t)b * g.N + n) * Q;
 			const double *pa = Cp + (size_t)g.v_cpos[e0] * Q, *pb = Cp + (size_t)g.v_cpos[e0 + 1] * Q;
@@ -429,7 +429,7 @@ bool nbl_bp256_applicable(const NblGraphDev &g, bool all_dc4) { return g.q == 25
 
 hipError_t nbl_launch_cn_bp256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 {
-	dim3 grid((unsigned)((long long)r.B * g.M)), block(64);
+	dim3 grid(nbl_xcd_grid(r.B, g.M)), block(64);
 	if (fused) cn_bp_q256_dc4_kernel<true><<<grid, block, 0, st>>>(g, w, r);
 	else cn_bp_q256_dc4_kernel<false><<<grid, block, 0, st>>>(g, w, r);
 	return hipGetLastError();

@@ -252,14 +252,17 @@ __global__ __launch_bounds__(64) void cn_bp_q64_dc4_kernel(NblGraphDev g, NblWor
 {
 	__shared__ __attribute__((aligned(16))) double smem[4][4 * Q]; // 2 KB per check: four permutation buffers, then operands + staging
 	const int lane = lane_id(), gi = lane >> 4, l = lane & 15;
-	const long long ci = (long long)blockIdx.x * 4 + gi;
+	// (g.M + 3) / 4 workgroups per codeword, all of them on one XCD (nbl_device.h); group gi of workgroup `unit` holds check
+	// 4 unit + gi
+	const NblXcdSlot xs = nbl_xcd_slot((g.M + 3) >> 2);
+	const int m = xs.unit * 4 + gi;
 	int b = -1;
-	if (ci < (long long)r.B * g.M) {
-		b = nbl_codeword(w, r, (int)(ci / g.M));
+	if (m < g.M) {
+		b = nbl_codeword(w, r, xs.slot);
 		if (b >= 0 && !r.fixed_iters && w.done[b]) b = -1;
 	}
 	if (b < 0) return; // (a whole group leaves; the others never look at its lanes)
-	const int m = (int)(ci % g.M), c0 = g.coff[m];
+	const int c0 = g.coff[m];
 	double *const sm = smem[gi];
 
 	double *V = w.v2c + (size_t)b * g.E * Q;
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(64) void cn_bp_q64_dc4_kernel(NblGraphDev g, NblWor
 		// post - c2v of this edge, damped 1/2 : 1/2 against the previous v2c when its hard decision moves.  The previous decision
 		// is what this stage recorded one iteration ago (w.edge_dec), so the previous v2c itself is loaded only in iteration 1
 		// (where it is L_ch) or when the decision moved.  Two edges at a time: their loads are issued before the first value is used.
-		const double *Cp = w.c2v_prev + (size_t)b * g.E * Q;
+		const double *Cp = w.c2v_prev + (w.c2v_prev_shared ? (size_t)0 : (size_t)b * g.E * Q); // (iteration 1: one shared block of zeros)
 #pragma unroll
 		for (int half = 0; half < 2; half++) {
 			double lch[2][4], ca[2][4], cb[2][4];
@@ -427,7 +430,7 @@ bool nbl_bp64_applicable(const NblGraphDev &g, bool all_dc4) { return g.q == 64 
 
 hipError_t nbl_launch_cn_bp64(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 {
-	dim3 grid((unsigned)(((long long)r.B * g.M + 3) / 4)), block(64);
+	dim3 grid(nbl_xcd_grid(r.B, (g.M + 3) >> 2)), block(64);
 	if (fused) cn_bp_q64_dc4_kernel<true><<<grid, block, 0, st>>>(g, w, r);
 	else cn_bp_q64_dc4_kernel<false><<<grid, block, 0, st>>>(g, w, r);
 	return hipGetLastError();

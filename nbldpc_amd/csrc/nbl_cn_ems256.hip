@@ -260,11 +260,10 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	// __shared__` every computed address pays a v_add with the link-time base)
 	__shared__ __attribute__((aligned(16))) char smem[3 * Q * 8 + 4 * NM * 8 + 4 * NM * 8];
 	const int lane = lane_id();
-	// XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  All checks of
-	// a codeword are given to ONE XCD, so the second read of every L_ch / c2v vector (each is used by two checks) can hit
-	// that L2.  Speed only: nothing depends on the placement.
-	const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-	const int m = idx % g.M, b = nbl_codeword(w, r, (idx / g.M) * 8 + xcd);
+	// XCD-aware mapping (nbl_device.h): all checks of a codeword run on ONE XCD, so the second read of every L_ch / c2v vector
+	// (each is used by two checks) can hit that XCD's L2.  Speed only: nothing depends on the placement.
+	const NblXcdSlot xs = nbl_xcd_slot(g.M);
+	const int m = xs.unit, b = nbl_codeword(w, r, xs.slot);
 	if (b < 0) return;
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m];
@@ -318,7 +317,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			v[j][3] = d1.y;
 		}
 	} else {
-		const double *Cp = w.c2v_prev + (size_t)b * g.E * Q;
+		const double *Cp = w.c2v_prev + (w.c2v_prev_shared ? (size_t)0 : (size_t)b * g.E * Q); // (iteration 1: one shared block of zeros)
 		// issue every load of the four edges before anything consumes one (24 x 16 B per lane in flight)
 		double2 l0[4], l1[4], a0[4], a1[4], b0[4], b1[4];
 		int nvar[4], eidx[4];
@@ -754,7 +753,7 @@ static void launch_nc(int nc, dim3 grid, dim3 block, hipStream_t st, const NblGr
 
 hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 {
-	dim3 grid((unsigned)((long long)((r.B + 7) / 8) * 8 * g.M)), block(64);
+	dim3 grid(nbl_xcd_grid(r.B, g.M)), block(64);
 	if (fused) {
 		switch (r.nm) {
 		case 8: launch_nc<8, true>(r.nc, grid, block, st, g, w, r); break;

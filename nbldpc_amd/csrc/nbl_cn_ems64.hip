@@ -82,14 +82,17 @@ __global__ __launch_bounds__(64) void cn_ems_q64_kernel(NblGraphDev g, NblWork w
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int lane = lane_id(), gi = lane >> 4, sl = lane & 15;
-	const long long ci = (long long)blockIdx.x * 4 + gi;
+	// (g.M + 3) / 4 workgroups per codeword, all of them on one XCD (nbl_device.h); group gi of workgroup `unit` holds check
+	// 4 unit + gi
+	const NblXcdSlot xs = nbl_xcd_slot((g.M + 3) >> 2);
+	const int m = xs.unit * 4 + gi;
 	int b = -1;
-	if (ci < (long long)r.B * g.M) {
-		b = nbl_codeword(w, r, (int)(ci / g.M));
+	if (m < g.M) {
+		b = nbl_codeword(w, r, xs.slot);
 		if (b >= 0 && !r.fixed_iters && w.done[b]) b = -1;
 	}
 	if (b < 0) return; // (a whole group leaves; the others never look at its lanes)
-	const int m = (int)(ci % g.M), c0 = g.coff[m], dc = g.coff[m + 1] - c0, nm = r.nm, mdc = g.maxdc;
+	const int c0 = g.coff[m], dc = g.coff[m + 1] - c0, nm = r.nm, mdc = g.maxdc;
 	char *base = smem + (size_t)gi * group_bytes(mdc, nm, layers);
 	double *U = (double *)base;              // [mdc][Q]   check-domain input vectors: U[j][h_j*a] = v2c_j[a], U[j][0] = 0
 	double *A = U + mdc * Q;                 // [layers][Q] DP layers
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(64) void cn_ems_q64_kernel(NblGraphDev g, NblWork w
 					for (int i = 0; i < 4; i++) vin[u * Q + sl + 16 * i] = (sl + 16 * i == 0) ? 0.0 : v[u][i];
 				}
 		} else {
-			const double *Cp = w.c2v_prev + (size_t)b * g.E * Q;
+			const double *Cp = w.c2v_prev + (w.c2v_prev_shared ? (size_t)0 : (size_t)b * g.E * Q); // (iteration 1: one shared block of zeros)
 			int4 row[2];
 			int n[2], e[2];
 			double L[2][4], x0[2][4], x1[2][4], x2[2][4];
@@ -390,7 +393,7 @@ hipError_t nbl_launch_cn_ems64(const NblGraphDev &g, const NblWork &w, const Nbl
 {
 	const int layers = nbl_ems_layers(g, r.nc);
 	const size_t lds = group_bytes(g.maxdc, r.nm, layers) * 4;
-	dim3 grid((unsigned)(((long long)r.B * g.M + 3) / 4)), block(64);
+	dim3 grid(nbl_xcd_grid(r.B, (g.M + 3) >> 2)), block(64);
 	if (fused) cn_ems_q64_kernel<true><<<grid, block, lds, st>>>(g, w, r, layers);
 	else cn_ems_q64_kernel<false><<<grid, block, lds, st>>>(g, w, r, layers);
 	return hipGetLastError();

@@ -66,12 +66,13 @@ template <int Q> __device__ __forceinline__ Ctx<Q> ctx_init(const NblGraphDev &g
 	const int lane = lane_id();
 	c.gi = lane >> P;
 	c.sl = lane & (Q - 1);
-	const long long ci = (long long)blockIdx.x * G + c.gi, total = (long long)r.B * g.M;
+	// (g.M + G - 1) / G workgroups per codeword, all of them on one XCD (nbl_device.h); group gi of workgroup `unit` holds check
+	// G unit + gi
+	const NblXcdSlot xs = nbl_xcd_slot((g.M + G - 1) / G);
+	const int m = xs.unit * G + c.gi;
 	c.b = -1;
-	int m = 0;
-	if (ci < total) {
-		c.b = nbl_codeword(w, r, (int)(ci / g.M));
-		m = (int)(ci % g.M);
+	if (m < g.M) {
+		c.b = nbl_codeword(w, r, xs.slot);
 		if (c.b >= 0 && !r.fixed_iters && w.done[c.b]) c.b = -1;
 	}
 	c.live = c.b >= 0;
@@ -119,7 +120,7 @@ __device__ __forceinline__ void for_each_input(const NblGraphDev &g, const NblWo
 #pragma unroll
 			for (int u = 0; u < CH; u++) vin[u * Q + sl] = (sl > 0) ? v[u] : 0.0;
 		} else {
-			const double *Cp = w.c2v_prev + (size_t)c.b * g.E * Q;
+			const double *Cp = w.c2v_prev + (w.c2v_prev_shared ? (size_t)0 : (size_t)c.b * g.E * Q); // (iteration 1: one shared block of zeros)
 			int4 row[CH];
 			int n[CH], e[CH], before[CH];
 			double L[CH], x0[CH], x1[CH], x2[CH], ov[CH];
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(64) void cn_bp_small_kernel(NblGraphDev g, NblWork 
 
 template <int Q> struct SmallLaunch {
 	static constexpr int G = 64 / Q;
-	static dim3 grid(const NblGraphDev &g, const NblRun &r) { return dim3((unsigned)(((long long)r.B * g.M + G - 1) / G)); }
+	static dim3 grid(const NblGraphDev &g, const NblRun &r) { return dim3(nbl_xcd_grid(r.B, (g.M + G - 1) / G)); }
 	static hipError_t tems(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 	{
 		const size_t lds = tems_small_group_bytes(Q, g.maxdc) * G;

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 	double (*Lc)[Q] = (double (*)[Q])(lds + DC * Q * 8);   // [2][Q] extrinsic minima of two output edges at a time (:1075-1102)
 
 	const int lane = lane_id();
-	const int b = nbl_codeword(w, r, blockIdx.x / g.M), m = blockIdx.x % g.M;
+	const NblXcdSlot xs = nbl_xcd_slot(g.M); // all checks of a codeword on one XCD (nbl_device.h)
+	const int b = nbl_codeword(w, r, xs.slot), m = xs.unit;
 	if (b < 0) return;
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m];
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 		} else {
 			// post = (L_ch + c2v_0) + c2v_1 of the edge's variable (NBLDPC.cpp:977-992), hard decision by the check that holds the
 			// variable's first edge, v2c = post - c2v of this edge, damped 1/4 : 3/4 when its hard decision moves (:1029-1052)
-			const double *Cp = w.c2v_prev + (size_t)b * g.E * Q;
+			const double *Cp = w.c2v_prev + (w.c2v_prev_shared ? (size_t)0 : (size_t)b * g.E * Q); // (iteration 1: one shared block of zeros)
 			const int n = g.c_var[c0 + d], e = g.c_epos[c0 + d], e0 = g.voff[n];
 			const double *pl = w.Lch + ((size_t)b * g.N + n) * Q;
 			const double *pa = Cp + (size_t)g.v_cpos[e0] * Q, *pb = Cp + (size_t)g.v_cpos[e0 + 1] * Q;
@@ -290,7 +291,7 @@ bool nbl_tems256_applicable(const NblGraphDev &g, bool all_dc4, int nr, int nc)
 
 hipError_t nbl_launch_cn_tems256(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 {
-	dim3 grid((unsigned)((long long)r.B * g.M)), block(64);
+	dim3 grid(nbl_xcd_grid(r.B, g.M)), block(64);
 	switch ((fused ? 4 : 0) + r.nc) {
 	case 1: cn_tems_q256_dc4_kernel<false, 1><<<grid, block, 0, st>>>(g, w, r); break;
 	case 2: cn_tems_q256_dc4_kernel<false, 2><<<grid, block, 0, st>>>(g, w, r); break;

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 	double (*const Lc)[Q] = (double (*)[Q])phased;          // [DC][Q] extrinsic minima of every output edge (:1075-1102), after the DP
 	static_assert(sizeof(phased) >= DC * Q * 8, "Lc must fit the phased region");
 	const int lane = lane_id();
-	const int b = nbl_codeword(w, r, blockIdx.x / g.M), m = blockIdx.x % g.M;
+	const NblXcdSlot xs = nbl_xcd_slot(g.M); // all checks of a codeword on one XCD (nbl_device.h)
+	const int b = nbl_codeword(w, r, xs.slot), m = xs.unit;
 	if (b < 0) return;
 	if (!r.fixed_iters && w.done[b]) return;
 	const int c0 = g.coff[m];
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 	double vin[DC], vmax[DC];
 	int varg[DC];
 	if (FUSED) {
-		const double *Cp = w.c2v_prev + (size_t)b * g.E * Q;
+		const double *Cp = w.c2v_prev + (w.c2v_prev_shared ? (size_t)0 : (size_t)b * g.E * Q); // (iteration 1: one shared block of zeros)
 		double l[DC], ca[DC], cb[DC], ov[DC];
 		int nvar[DC], eidx[DC], before[DC];
 		bool ownA[DC];
@@ -259,7 +260,7 @@ bool nbl_tems64_applicable(const NblGraphDev &g, bool all_dc4, int nr, int nc)
 
 hipError_t nbl_launch_cn_tems64(const NblGraphDev &g, const NblWork &w, const NblRun &r, bool fused, hipStream_t st)
 {
-	dim3 grid((unsigned)((long long)r.B * g.M)), block(64);
+	dim3 grid(nbl_xcd_grid(r.B, g.M)), block(64);
 	switch ((fused ? 4 : 0) + r.nc) {
 	case 1: cn_tems_q64_dc4_kernel<false, 1><<<grid, block, 0, st>>>(g, w, r); break;
 	case 2: cn_tems_q64_dc4_kernel<false, 2><<<grid, block, 0, st>>>(g, w, r); break;

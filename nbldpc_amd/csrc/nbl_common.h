@@ -26,7 +26,7 @@ struct NblGraphDev {
 	const int *c_h;     // [E] check-major edge coefficient
 	const int *c_hinv;  // [E] inverse coefficient
 	const uint8_t *mul; // [q*q] GF multiplication table (syndrome kernel)
-	const int *c_nbr;   // [E][4] q <= 32, variable degrees <= 3 only (else NULL): for check-major edge e of variable n the c2v slots of
+	const int *c_nbr;   // [E][4] q <= 64, variable degrees 2 and 3 only (else NULL): for check-major edge e of variable n the c2v slots of
 	                    // n's edges in order (third = -1 at degree 2) and, in [3], 1 if e is n's first edge (nbl_cn_small.hip, fused)
 	const unsigned long long *ems_toff; // [E][64] GF(256), all checks of degree 4 only (else NULL): for check-major edge e and lane l the
 	                    // byte offsets 8 * (h_e * a) of a = 2l, 2l+1, 128+2l, 129+2l, 16 bits each (nbl_cn_ems256.hip)
@@ -35,6 +35,7 @@ struct NblGraphDev {
 struct NblWork {
 	double *Lch, *v2c, *c2v, *post; // post only when state recording is on
 	const double *c2v_prev;         // fused EMS iteration: c2v of the previous iteration (read), c2v = this iteration (written)
+	int c2v_prev_shared;            // 1: c2v_prev is ONE [E][q] block that every codeword reads (iteration 1: the all-zero c2v of iteration 0)
 	int store_v2c;                  // fused EMS iteration: also write v2c (state read-back only)
 	int *dec, *out, *iters;
 	int *edge_dec;                  // fused damped iterations (T-EMS, BP): hard decision of every v2c vector of the previous iteration

@@ -16,6 +16,22 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // codeword of grid slot `slot` (wave-uniform), -1 = nothing to do.  With the active list (early exit on large batches) the grid
 // only covers the codewords that were still iterating after the previous window.
+// XCD-aware grids of the fused check-node kernels.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with
+// its own L2.  A fused iteration reads every L_ch / c2v vector of a codeword twice or three times (once per check the variable
+// joins): all `units` workgroups of a codeword slot are therefore given to ONE XCD, so that the later reads can hit that L2
+// instead of HBM.  Speed only: nothing depends on the placement.  The grid is rounded up to whole groups of 8 slots; slots
+// beyond the batch find no codeword (nbl_codeword returns -1).
+struct NblXcdSlot { int slot, unit; };
+__device__ __forceinline__ NblXcdSlot nbl_xcd_slot(int units)
+{
+	const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+	NblXcdSlot s;
+	s.slot = (idx / units) * 8 + xcd;
+	s.unit = idx % units;
+	return s;
+}
+inline unsigned nbl_xcd_grid(int B, int units) { return (unsigned)((long long)((B + 7) / 8) * 8 * units); }
+
 __device__ __forceinline__ int nbl_codeword(const NblWork &w, const NblRun &r, int slot)
 {
 	if (slot >= r.B) return -1;

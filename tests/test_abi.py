@@ -59,6 +59,12 @@ def test_create_rejects_bad_arguments_before_touching_the_device():
     with pytest.raises(nb.NblError) as e:
         _create(bad, method=nb.METHOD_EMS, max_iter=5, ems_nm=8)
     assert e.value.status == -1
+    # GF(512): the reference ships arithmetic tables for it but no code; a valid request this library cannot serve (-2), not a
+    # malformed one (-1)
+    big = _ring_code(512, 8, 4)
+    with pytest.raises(nb.NblError) as e:
+        _create(big, method=nb.METHOD_EMS, max_iter=5, ems_nm=8, gf=(np.zeros((512, 512), np.uint16), np.zeros(512, np.uint16)))
+    assert e.value.status == -2 and "GF(256)" in str(e.value)
     # GF table that is not a field table
     mul, inv = nb.datafiles.gf_tables(16)
     mul = [row[:] for row in mul]

@@ -111,6 +111,22 @@ def test_channel_entry_points_edge_cases(tmp_path):
             assert np.array_equal(a, b[:B]), B
         r2, _ = dec.channel(txi[:B], state[:B], sigma)
         assert np.array_equal(r2.view(np.uint64), rx[:B].view(np.uint64))
+    # a constellation index beyond the modulation order is refused (it would index past the points on the device)
+    bad = txi.copy()
+    bad[P - 1, L - 1] = 2
+    with pytest.raises(nb.NblError) as e:
+        dec.channel(bad, state, sigma)
+    assert e.value.status == -1 and "tx_index" in str(e.value)
+    # re-configured demodulator with MORE symbols per lane (256-ary, L = N  ->  BPSK, L = 8 N) at the same batch size: the
+    # channel's buffers follow the new L (their capacity was keyed on the batch size alone)
+    pts256 = np.array([[x[1], x[2]] for x in sorted(df.constellations()["GRAY_256QAM"])])
+    dec2 = nb.Decoder(code, nb.METHOD_EMS, 10, ems_nm=16, ems_nc=3)
+    dec2.set_demodulator(q, code.N, np.arange(code.N), pts256)
+    dec2.channel(np.zeros((P, code.N), np.uint8), state, sigma)
+    dec2.set_demodulator(2, L, np.arange(L), points)
+    r3, _ = dec2.channel(txi, state, sigma)
+    assert np.array_equal(r3.view(np.uint64), rx.view(np.uint64))
+    dec2.close()
     out, conv, it = dec.decode_noise(txi[:0], state[:0], sigma)   # empty batch: nothing to do, no error
     assert out.shape == (0, code.N)
     with pytest.raises(nb.NblError):

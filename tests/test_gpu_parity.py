@@ -450,6 +450,66 @@ def test_field_sizes_without_a_shipped_code(oracle, q, method):
         dec.close()
 
 
+def _code_with_degree_one_variables(q, seed, M=12):
+    """Synthetic graph with variables of degree 1, 2 and 3: every check gets one private degree-1 variable, the rest is the
+    irregular graph of _random_code.  Returns (nb.Code, oracle edge tuple)."""
+    base, _ = _random_code(q, seed, M=M, degs=(3, 4))
+    rng = np.random.default_rng(seed + 1)
+    off = np.concatenate([[0], np.cumsum(base.var_deg)])
+    var_rows = [[(int(base.var_chk[e]) + 1, int(base.var_h[e])) for e in range(off[n], off[n + 1])] for n in range(base.N)]
+    for m in range(M):
+        var_rows.append([(m + 1, int(rng.integers(1, q)))])
+    N = len(var_rows)
+    chk_rows = [[] for _ in range(M)]
+    ev, ec, eh = [], [], []
+    for n, r in enumerate(var_rows):
+        for m1, h in r:
+            chk_rows[m1 - 1].append((n + 1, h))
+            ev.append(n); ec.append(m1 - 1); eh.append(h)
+    code = nb.Code(spec=dict(N=N, M=M, q=q, var_rows=var_rows, chk_rows=chk_rows))
+    return code, (N, M, q, np.array(ev, np.int32), np.array(ec, np.int32), np.array(eh, np.int32))
+
+
+@pytest.mark.parametrize("method", ["ems", "tems", "bp"])
+@pytest.mark.parametrize("q", [16, 64])
+def test_degree_one_variables(oracle, q, method):
+    """Codes with degree-1 variables (accepted by nbl_create: var_deg >= 1) on the small-field / GF(64) shapes.  The fused
+    iteration of nbl_cn_small.hip / nbl_cn_ems64.hip adds the second c2v vector of a variable unconditionally, so such a code
+    must take the separate variable-node launch (nbl_create builds g.c_nbr for variable degrees 2 and 3 only; ADVICE round 2:
+    the fused loaders read out of bounds and decided wrongly here).  Default path, general kernels and the small-field check
+    node behind the separate VN pass against the oracle: EMS / T-EMS bit for bit, log-QSPA within 1e-9."""
+    code, edges = _code_with_degree_one_variables(q, 4100 + q)
+    assert code.var_deg.min() == 1 and code.var_deg.max() == 3
+    N = code.N
+    rng = np.random.default_rng(77 + q)
+    L = rng.normal(-1.5, 3, (4, N, q - 1))
+    L[2] = np.round(rng.normal(-1, 2, (N, q - 1)))
+    L[3] = 0.0
+    meth, ometh, kw = {"ems": (nb.METHOD_EMS, oracle.EMS, dict(ems_nm=min(q, 6), ems_nc=2, ems_factor=1.1, ems_offset=0.1)),
+                       "tems": (nb.METHOD_TEMS, oracle.TEMS, dict(tems_nr=2, tems_nc=3, tems_factor=1.0, tems_offset=0.0)),
+                       "bp": (nb.METHOD_BP, oracle.BP, dict())}[method]
+    iters = 3
+    od = oracle.Decoder(oracle.Code(edges=edges), oracle.GF(q), ometh, iters, oracle.CANONICAL, **kw)
+    ref = []
+    for b in range(L.shape[0]):
+        r, o, it = od.decode(L[b])
+        ref.append((r, o.copy(), it, [x.copy() for x in od.state()]))
+    for variant in (0, 1, 2):
+        dec = nb.Decoder(code, meth, iters, **kw)
+        _force_generic(dec, variant)
+        dec.record_state(True)
+        out, conv, its = dec.decode(L)
+        for b in range(L.shape[0]):
+            r, o, it, st = ref[b]
+            assert (conv[b], its[b]) == (r, it) and np.array_equal(out[b], o), (variant, b)
+            for a, x in zip(dec.read_state(b), st):
+                if method == "bp":
+                    assert np.max(np.abs(a - x)) <= LLR_TOL * max(1.0, np.max(np.abs(x))), (variant, b)
+                else:
+                    assert np.array_equal(a, x), (variant, b)
+        dec.close()
+
+
 def test_tems_gf256_nr3_nc2_integer_llr_regression(oracle):
     """Named regression guard: GF(256), nr = 3, nc = 2, integer LLRs -- the shape on which the first layout of the
     GF(256) T-EMS kernel's DP state produced wrong path codes at -O2/-O3 (nbl_cn_tems256.hip header; attributed to hipcc's late
