@@ -123,7 +123,42 @@ def cpu_baseline_reference(nb, nm, nc, max_iter, threads, frames=4):
                       f"{wall:.1f} s wall incl. set-up)"}
 
 
-PMC_SUMMARY = os.path.join("profiles", "r02_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r03_summary.json")
+# the other BASELINE.json configurations that fit one GPU: (name in tools/bench_config.py, batch, timed
+# decodes, Eb/N0) -- one short fixed-iteration pass each AFTER the headline's timed region, reported under "other_configs"
+OTHER_CONFIGS = (("cfg2", 4096, 4, None), ("cfg4", 8192, 2, 3.0), ("cfg5", 2048, 1, 4.0))
+
+
+def other_configs(device):
+    import bench_config
+    labels = {"cfg2": "configs[1]: divsalar.UNBLDPC.128.64.GF.256 over BPSK, EMS nm=16 nc=3, 50 fixed iterations, batch 4096",
+              "cfg4": "configs[3]: BDS.576.288.GF.64 over GRAY_64QAM, T-EMS nr=2 nc=3, 50 fixed iterations, Eb/N0 3 dB, batch 8192",
+              "cfg5": "configs[4]: divsalar.CNBLDPC.512.256.GF.256 over GRAY_256QAM, full log-QSPA, 100 fixed iterations, Eb/N0 4 dB, "
+                      "batch 2048 on this GPU (BASELINE: 8192 across 8)"}
+    res = []
+    for name, B, steps, ebn0 in OTHER_CONFIGS:
+        r = bench_config.run_config(name, B, steps, ebn0, device)
+        res.append({"workload": labels[name], "value": r["codewords_per_s"], "unit": "codewords/s", "ms_per_step": r["ms_per_batch"],
+                    "ms_per_launch": r["cn_ms_per_launch"], "converged_frac": r["converged_frac"], "data": "synthetic (all-zero codeword + randn noise)",
+                    "roofline": {"kernel": r["kernel"], "bound": "hbm", "achieved": r["cn_achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": (r["cn_achieved_GBps"] or 0.0) / HBM_PEAK_GBS, "bytes_per_launch": r["cn_algorithmic_bytes_per_launch"]}})
+    return res
+
+
+def limiter_text():
+    """What the dominant kernel waits for, from the committed counter passes (not measured in this run): vector-ALU busy share and
+    LDS-port busy share of the kernel at its four waves per SIMD (16 per CU, one LDS port per CU)."""
+    path = os.path.join(ROOT, PMC_SUMMARY)
+    if not os.path.exists(path):
+        return None
+    for name, v in json.load(open(path)).get("sq_pmc", {}).items():
+        if "cn_ems_q256_dc4_kernel<32, true" in name and "per_wave" in v:
+            pw = v["per_wave"]
+            valu = pw["valu_busy_of_wave_lifetime_x4_waves"]
+            lds = 16.0 * pw["lds_active_cycles"] / pw["wave_cycles"]  # 16 waves of a CU share its LDS port
+            return (f"fp64 valu issue ({100 * valu:.0f} % busy) + lds port ({100 * lds:.0f} %), not hbm ({PMC_SUMMARY}: "
+                    f"{pw['valu_insts']:.0f} VALU / {pw['salu_insts']:.0f} SALU / {pw['lds_insts']:.0f} LDS instructions per check-wave)")
+    return None
 
 
 def pmc_traffic(fused, B):
@@ -155,6 +190,7 @@ def main():
                          "randn: all-zero codeword + torch.randn noise")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
+    ap.add_argument("--other-configs", type=int, default=-1, help="1 / 0: also run BASELINE configs 2, 4, 5 after the timed region (default: at N = 1)")
     args = ap.parse_args()
 
     import torch
@@ -241,7 +277,7 @@ def main():
         "roofline": {"kernel": "cn_ems_q256_dc4_kernel<32, fused>" if fused else "cn_ems_q256_dc4_kernel<32>", "bound": "hbm", "achieved": cn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": cn_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": PMC_SUMMARY + " (rocprofv3 --pmc passes of this command; not measured in this run)" if traffic else None,
                      "hbm_actual_GBps": (traffic / (cn_ms * 1e-3) / 1e9) if (traffic and cn_ms > 0) else None,
-                     "limiter": "fp64 valu issue (~84 % busy) + lds port (~75 %), not hbm (profiles/r02_summary.json)",
+                     "limiter": limiter_text(),
                      "bytes_per_launch": cn_bytes_launch, "ms_per_launch": cn_ms},
     }
     if rank == 0 and world == 1 and args.cpu_sample != 0:
@@ -256,9 +292,13 @@ def main():
         port = cpu_baseline_port(nb, L[:n].cpu().numpy(), args.nm, args.nc, args.iters, threads)
         res["cpu_baseline"] = ref if ref is not None else port
         res["cpu_baseline_port"] = port
+    dec.close()
+    if rank == 0 and world == 1 and args.other_configs != 0:
+        del L, out, conv, its, tx_dev
+        torch.cuda.empty_cache()
+        res["other_configs"] = other_configs(local_rank)
     if rank == 0:
         print(json.dumps(res))
-    dec.close()
     ranks.finish(rk)
 
 

@@ -285,11 +285,15 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	// per-section cycle stamps (tools/stamps.py): compiled in only with -DNBL_EMS_STAMPS -- the accumulators
 	// live in SGPRs for the whole kernel and push the selection code into SGPR spills
 #ifdef NBL_EMS_STAMPS
-	unsigned long long st_t0 = 0, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long st_t0 = 0, st_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	const bool st_on = (w.stamps != nullptr) && ((blockIdx.x & 63) == 0);
 #define STAMP(i) do { if (st_on) { unsigned long long t1_ = clock64(); st_acc[i] += t1_ - st_t0; st_t0 = t1_; } } while (0)
 #define STAMP_COUNT(i) do { if (st_on) st_acc[i]++; } while (0)
 	if (st_on) st_t0 = clock64();
+#elif defined(NBL_EMS_MARKS)
+	// static instruction budget (tools/isa_budget.py): a comment line in the ISA at every section boundary
+#define STAMP(i) asm volatile("; NBLMARK " #i)
+#define STAMP_COUNT(i) do { } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #define STAMP_COUNT(i) do { } while (0)
@@ -509,6 +513,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 				for (int i = 0; i < 4; i++) member[i] = __ballot(bk[j][i] <= bstar);
 			} else {
 				// (no bucket reaches nm -- cannot happen with finite inputs: every entry is a candidate)
+				STAMP_COUNT(10);
 				SelState ss;
 #pragma unroll
 				for (int i = 0; i < 4; i++) { ss.cand[i] = reach ? __ballot(bk[j][i] == bstar) : ~0ull; ss.gt[i] = ss.eq[i] = 0; }
@@ -637,13 +642,14 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		auto run = [&](int k0, int k1, auto swapped, auto upper) {
 			int k = k0;
 			for (; k + UN <= k1; k += UN) {
+				STAMP_COUNT(11);
 				ListEnt en[UN];
 #pragma unroll
 				for (int u = 0; u < UN; u++) en[u] = entry(k + u);
 #pragma unroll
 				for (int u = 0; u < UN; u++) body(en[u], swapped, upper);
 			}
-			for (; k < k1; k++) body(entry(k), swapped, upper);
+			for (; k < k1; k++) { STAMP_COUNT(12); body(entry(k), swapped, upper); }
 		};
 		run(0, nA[jc], std::false_type{}, std::false_type{});
 		run(nA[jc], n0[jc], std::false_type{}, std::true_type{});
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 
 #ifdef NBL_EMS_STAMPS
 	if (st_on && lane == 0) {
-		for (int i = 0; i < 12; i++) atomicAdd(&w.stamps[i], st_acc[i]);
+		for (int i = 0; i < 15; i++) atomicAdd(&w.stamps[i], st_acc[i]);
 		atomicAdd(&w.stamps[15], 1ull);
 	}
 #endif

@@ -55,17 +55,24 @@ def synth(code, B, ebn0, mod, dev):
     return ((2 * r[:, :, None, :] - c[0] - c[1:]) * d).sum(-1) / (2 * sigma ** 2)
 
 
-def main():
-    name = sys.argv[1]
+KERNEL = {"cfg1": "cn_bp_small_kernel<16, fused>", "cfg2": "cn_ems_q256_dc4_kernel<16, fused>", "cfg3": "cn_ems_q256_dc4_kernel<32, fused>",
+          "cfg3nc2": "cn_ems_q256_dc4_kernel<32, fused, nc 2>", "cfg4": "cn_tems_q64_dc4_kernel<fused, 3>", "cfg5": "cn_bp_q256_dc4_kernel<fused>",
+          "tems256": "cn_tems_q256_dc4_kernel<fused, 3>", "ems64": "cn_ems_q64_kernel<fused>", "bp64": "cn_bp_q64_dc4_kernel<fused>",
+          "ems16": "cn_ems_small_kernel<16, fused>", "tems16": "cn_tems_small_kernel<16, fused>", "bp16": "cn_bp_small_kernel<16, fused>"}
+
+
+def run_config(name, B=None, steps=2, ebn0=None, device=0):
+    """One configuration at fixed iterations with HBM-resident inputs: codewords/s over `steps` timed decodes (wall clock around
+    synchronised launches), the check-node kernel's mean launch time (HIP events on the launch stream) and its algorithmic-bytes
+    roofline (8(q-1)(N + 4E + D E) bytes per codeword and iteration, D = 1 for the damped methods)."""
     c = CFG[name]
-    B = int(sys.argv[2]) if len(sys.argv) > 2 else c["batch"]
-    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-    if len(sys.argv) > 4:
-        c = dict(c, ebn0=float(sys.argv[4]))
-    dev = torch.device("cuda", 0)
+    B = B or c["batch"]
+    if ebn0 is not None:
+        c = dict(c, ebn0=float(ebn0))
+    dev = torch.device("cuda", device)
     code = nb.Code(c["code"])
     L = synth(code, B, c["ebn0"], c["mod"], dev).contiguous()
-    dec = nb.Decoder(code, c["method"], c["iters"], fixed_iters=1, max_batch=B, **c["kw"])
+    dec = nb.Decoder(code, c["method"], c["iters"], fixed_iters=1, max_batch=B, device=device, **c["kw"])
     out = torch.zeros((B, code.N), dtype=torch.int32, device=dev)
     conv = torch.zeros(B, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
@@ -82,12 +89,30 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     q, N, E, I = code.q, code.N, code.E, c["iters"]
-    bytes_cw = 8 * (q - 1) * (N + I * (N + 4 * E + c["D"] * E)) + 4 * N + 4
+    bytes_iter = 8 * (q - 1) * (N + 4 * E + c["D"] * E)
+    bytes_cw = 8 * (q - 1) * N + I * bytes_iter + 4 * N + 4
     cws = B * steps / dt
-    print(json.dumps({"config": name, "code": c["code"], "method": c["method"], "iters": I, "batch": B, "codewords_per_s": cws,
-                      "ms_per_batch": dt / steps * 1e3, "algorithmic_GBps": cws * bytes_cw / 1e9, "hbm_frac": cws * bytes_cw / 8e12,
-                      "converged_frac": float(conv.float().mean().item()), "ebn0": c["ebn0"],
-                      "phase_ms": {"vn": phase_ms[0], "syndrome": phase_ms[1], "cn": phase_ms[2]}, "launches": launches}))
+    cn_ms = phase_ms[2] / max(launches[2], 1)
+    fused = phase_ms[0] == 0.0
+    res = {"config": name, "code": c["code"], "method": c["method"], "iters": I, "batch": B, "codewords_per_s": cws,
+           "ms_per_batch": dt / steps * 1e3, "algorithmic_GBps": cws * bytes_cw / 1e9, "hbm_frac": cws * bytes_cw / 8e12,
+           "converged_frac": float(conv.float().mean().item()), "ebn0": c["ebn0"],
+           "phase_ms": {"vn": phase_ms[0], "syndrome": phase_ms[1], "cn": phase_ms[2]}, "launches": launches,
+           "cn_ms_per_launch": cn_ms, "fused": fused, "kernel": KERNEL.get(name, "?") if fused else "(unfused)",
+           "cn_algorithmic_bytes_per_launch": B * bytes_iter if fused else None,
+           "cn_achieved_GBps": (B * bytes_iter / (cn_ms * 1e-3) / 1e9) if (fused and cn_ms > 0) else None}
+    dec.close()
+    del L, out, conv
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    name = sys.argv[1]
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    ebn0 = float(sys.argv[4]) if len(sys.argv) > 4 else None
+    print(json.dumps(run_config(name, B, steps, ebn0)))
 
 
 if __name__ == "__main__":

@@ -27,3 +27,10 @@ print("quickselect loop iterations per check:", out[9] / n)
 for i, nme in enumerate(names):
     print(f"{nme:14s} {out[i]/n:10.0f} cycles/check  {100*out[i]/tot:5.1f}%")
 print("total", tot / n, "cycles per check-wave (s_memtime ticks), samples", n)
+# run statistics for tools/isa_budget.py (gather_conv runs twice per check: the trips are per check, both calls together)
+import json
+counts = dict(qs_trips_per_check=out[9] / n, inexact_edges_per_check=out[10] / n, un4_trips_per_check=out[11] / n, rem_trips_per_check=out[12] / n,
+              batch=B, samples=int(n), workload="bench.py inputs (config 3, 1.0 dB), iteration 1..10 of a fixed-iteration decode")
+print(json.dumps(counts))
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(counts, open("gpurun_out/r03_stamps_counts.json", "w"), indent=1)
