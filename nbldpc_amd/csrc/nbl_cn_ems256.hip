@@ -27,6 +27,10 @@
 #include "nbl_device.h"
 #include "nbl_kernels.h"
 
+#ifndef NBL_WHATIF
+#define NBL_WHATIF 0 // 1..7: diagnostic builds that leave one kind of work out (tools/whatif.sh); the results are wrong on purpose
+#endif
+
 namespace {
 
 constexpr int Q = 256;
@@ -258,7 +262,13 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	constexpr int LOGNM = (NM == 8) ? 3 : (NM == 16) ? 4 : 5;
 	// static LDS: its base is a compile-time constant, so computed addresses fold into the ds_* offset fields (with `extern
 	// __shared__` every computed address pays a v_add with the link-time base)
+#if NBL_WHATIF == 5   // diagnostic: three waves per SIMD (13 KB of LDS per wave)
+	__shared__ __attribute__((aligned(16))) char smem[13 * 1024];
+#elif NBL_WHATIF == 6 // diagnostic: two waves per SIMD (19 KB)
+	__shared__ __attribute__((aligned(16))) char smem[19 * 1024];
+#else
 	__shared__ __attribute__((aligned(16))) char smem[3 * Q * 8 + 4 * NM * 8 + 4 * NM * 8];
+#endif
 	const int lane = lane_id();
 	// XCD-aware mapping (nbl_device.h): all checks of a codeword run on ONE XCD, so the second read of every L_ch / c2v vector
 	// (each is used by two checks) can hit that XCD's L2.  Speed only: nothing depends on the placement.
@@ -333,9 +343,15 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			const double2 *pl = (const double2 *)(w.Lch + ((size_t)b * g.N + n) * Q);
 			const double2 *pa = (const double2 *)(Cp + (size_t)cpA * Q);
 			const double2 *pb = (const double2 *)(Cp + (size_t)cpB * Q);
+#if NBL_WHATIF == 4 // diagnostic (wrong results): no HBM reads, inputs made up from the addresses
+			l0[j].x = (double)(long long)(pl + lane) * -1e-9; l0[j].y = l0[j].x * 1.5; l1[j].x = l0[j].x * 0.7; l1[j].y = l0[j].x * 0.3;
+			a0[j].x = (double)(long long)(pa + lane) * -1e-9; a0[j].y = a0[j].x * 1.25; a1[j].x = a0[j].x * 0.6; a1[j].y = a0[j].x * 0.2;
+			b0[j].x = (double)(long long)(pb + lane) * -1e-9; b0[j].y = b0[j].x * 1.125; b1[j].x = b0[j].x * 0.9; b1[j].y = b0[j].x * 0.4;
+#else
 			l0[j] = pl[lane]; l1[j] = pl[64 + lane];
 			a0[j] = pa[lane]; a1[j] = pa[64 + lane];
 			b0[j] = pb[lane]; b1[j] = pb[64 + lane];
+#endif
 			nvar[j] = n; eidx[j] = e;
 			ownA[j] = (e == e0); // this check is the variable's first edge
 		}
@@ -344,10 +360,13 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			const int n = nvar[j], e = eidx[j];
 			double post[4] = {(l0[j].x + a0[j].x) + b0[j].x, (l0[j].y + a0[j].y) + b0[j].y, (l1[j].x + a1[j].x) + b1[j].x,
 			                  (l1[j].y + a1[j].y) + b1[j].y};
-			v[j][0] = post[0] - (ownA[j] ? a0[j].x : b0[j].x);
-			v[j][1] = post[1] - (ownA[j] ? a0[j].y : b0[j].y);
-			v[j][2] = post[2] - (ownA[j] ? a1[j].x : b1[j].x);
-			v[j][3] = post[3] - (ownA[j] ? a1[j].y : b1[j].y);
+			// (ownA is wave-uniform: a branch, not eight per-lane selects)
+			if (ownA[j]) {
+				v[j][0] = post[0] - a0[j].x; v[j][1] = post[1] - a0[j].y; v[j][2] = post[2] - a1[j].x; v[j][3] = post[3] - a1[j].y;
+			} else {
+				asm volatile(""); // (keeps the arms apart: hipcc folds this diamond back into selects otherwise)
+				v[j][0] = post[0] - b0[j].x; v[j][1] = post[1] - b0[j].y; v[j][2] = post[2] - b1[j].x; v[j][3] = post[3] - b1[j].y;
+			}
 			if (lane == 0) v[j][0] = 0.0;
 			if (ownA[j]) {
 				// hard decision (DecideLLRVector :1542-1562): lowest symbol among the maxima, 0 unless the maximum is positive
@@ -389,7 +408,10 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		mtop[j] = wave_max_exact(loc, k, wave_max_i32(k));
 		// 64 distinct entries are >= the smallest lane maximum, so the nm-th best (nm <= 64) is too; the key of that minimum is
 		// taken one float step down (rounding may have gone up) -- any lower bound will do
-		const double lf = dmin((double)unkey32(wave_min_i32(k)), 3.0e38); // (a float infinity must not become the bound)
+		// (a float infinity must not become the bound: the key is clamped on the scalar unit, below the key of FLT_MAX)
+		constexpr int KEY_3E38 = 0x7f61b1e6; // key32(3.0e38)
+		const int kmin = wave_min_i32(k);
+		const double lf = (double)unkey32(kmin < KEY_3E38 ? kmin : KEY_3E38);
 		lmin[j] = ((lf - (mtop[j] - lf) * 0x1p-20) - __builtin_fabs(lf) * 0x1p-22) - 0x1p-120; // (margins: float rounding, rcp in the bucket scale)
 		uint64_t eqm[4];
 #pragma unroll
@@ -459,6 +481,8 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	if (NC >= 2) { // conf(nm,1) needs no lists: it is contained in conf(q,1)
 		int bk[4][4];
 		int *H = (int *)B0; // [4 edges][256 buckets] (spans B0 and B1); lane l reads buckets 4l .. 4l+3 of every edge
+		int one;            // the increment of the sixteen histogram atomics, held in ONE register (hipcc re-materialises a literal 1 per atomic)
+		asm volatile("v_mov_b32 %0, 1" : "=v"(one));
 		WSYNC();
 		{
 			int4 z4 = {0, 0, 0, 0};
@@ -474,8 +498,13 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			const double scale = 256.0 * __builtin_amdgcn_rcp(mtop[j] - lmin[j]);
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
-				bk[j][i] = (int)dmin((mtop[j] - v[j][i]) * scale, 256.0);
-				if (bk[j][i] < 256) atomicAdd(&H[j * 256 + bk[j][i]], 1);
+				// v_cvt_i32_f64 saturates (and maps NaN to 0): no FP64 minimum against a constant that would have to be materialised in
+				// a register pair.  A bucket >= 256 lies below the lower bound and is not counted; every later use compares bk against
+				// a bucket <= 255, so it needs no clamp either
+				int bi;
+				asm("v_cvt_i32_f64 %0, %1" : "=v"(bi) : "v"((mtop[j] - v[j][i]) * scale));
+				bk[j][i] = bi;
+				if (bi < 256) __hip_atomic_fetch_add(&H[j * 256 + bi], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
 		}
 		WSYNC();
@@ -617,15 +646,27 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			double2 ra[NP], rb[NP];
 #pragma unroll
 			for (int p = 0; p < NP; p++) {
+#if NBL_WHATIF == 1 // diagnostic (wrong results): the gathers without their LDS reads
+				ra[p].x = acc[p][1]; ra[p].y = acc[p][0]; rb[p].x = acc[p][3]; rb[p].y = acc[p][2];
+				asm volatile("" : "+v"(ra[p].x), "+v"(ra[p].y), "+v"(rb[p].x), "+v"(rb[p].y) : "v"(ad));
+#else
 				ra[p] = *(const double2 *)(Pb + p * (Q * 8) + ad + (HI ? 1024 : 0));
 				rb[p] = *(const double2 *)(Pb + p * (Q * 8) + ad + (HI ? 0 : 1024));
+#endif
 			}
 #pragma unroll
 			for (int p = 0; p < NP; p++) {
+#if NBL_WHATIF == 2 // diagnostic (wrong results): the gathers without their additions
+				acc[p][0] = dmax(acc[p][0], (SW ? ra[p].y : ra[p].x));
+				acc[p][1] = dmax(acc[p][1], (SW ? ra[p].x : ra[p].y));
+				acc[p][2] = dmax(acc[p][2], (SW ? rb[p].y : rb[p].x));
+				acc[p][3] = dmax(acc[p][3], (SW ? rb[p].x : rb[p].y));
+#else
 				acc[p][0] = dmax(acc[p][0], (SW ? ra[p].y : ra[p].x) + en.v);
 				acc[p][1] = dmax(acc[p][1], (SW ? ra[p].x : ra[p].y) + en.v);
 				acc[p][2] = dmax(acc[p][2], (SW ? rb[p].y : rb[p].x) + en.v);
 				acc[p][3] = dmax(acc[p][3], (SW ? rb[p].x : rb[p].y) + en.v);
+#endif
 			}
 		};
 		// the list lives in the registers of lanes 0..NM-1 (one entry each); an entry reaches the whole wave through v_readlane
@@ -689,9 +730,19 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 #pragma unroll
 			for (int it = 0; it < ROUNDS; it++) {
 				const ListEnt eb1 = list_at(1, it * PER + (lane >> LOGNM)), eb2 = list_at(2, it * PER + (lane >> LOGNM));
+#if NBL_WHATIF == 3 // diagnostic (wrong results): the pair convolutions without their LDS atomics
+				double keep = (ea0.v + eb1.v) + ((ea0.v + eb2.v) + (ea1.v + eb2.v));
+				int keepa = (ea0.t8 ^ eb1.t8) + (ea0.t8 ^ eb2.t8) + (ea1.t8 ^ eb2.t8);
+				asm volatile("" : : "v"(keep), "v"(keepa));
+#elif NBL_WHATIF == 7 // diagnostic (wrong results): plain stores to the same addresses instead of the atomic maxima
+				*(volatile double *)((char *)B0 + (ea0.t8 ^ eb1.t8)) = ea0.v + eb1.v;
+				*(volatile double *)((char *)B1 + (ea0.t8 ^ eb2.t8)) = ea0.v + eb2.v;
+				*(volatile double *)((char *)B2 + (ea1.t8 ^ eb2.t8)) = ea1.v + eb2.v;
+#else
 				__hip_atomic_fetch_max((double *)((char *)B0 + (ea0.t8 ^ eb1.t8)), ea0.v + eb1.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				__hip_atomic_fetch_max((double *)((char *)B1 + (ea0.t8 ^ eb2.t8)), ea0.v + eb2.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				__hip_atomic_fetch_max((double *)((char *)B2 + (ea1.t8 ^ eb2.t8)), ea1.v + eb2.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 			}
 			WSYNC();
 		}
