@@ -132,6 +132,19 @@ FER_SETS = {
                                snr_begin=1.5, snr_step=0.5, snr_stop=2.0, constellation="BPSK", min_sim_cycle=120)),
     "bp_gf16_u256_p8": ("O0", dict(gfq=16, code=U256_16, method=1, max_iter=20, parallel=8,
                                    snr_begin=2.0, snr_step=0.5, snr_stop=3.0, constellation="BPSK", min_sim_cycle=2000)),
+    # the two caller-path features no other anchor touches.
+    # Puncturing (NBLDPC.cpp:163-176, Comm.cpp:290-308, :348-357): `Puncture Degree: 3` removes every degree-3 variable of the
+    # GF(16) 256.128 code from the channel (its bits are not sent; the demodulator gives them LLR 0).
+    "ems_gf16_u256_punct3": ("O2", dict(gfq=16, code=U256_16, puncture_degree=3, method=2, max_iter=20, parallel=8, ems_nm=8, ems_nc=3,
+                                        snr_begin=3.0, snr_step=1.0, snr_stop=4.0, constellation="BPSK", min_sim_cycle=500)),
+    "bp_gf16_u256_punct3": ("O0", dict(gfq=16, code=U256_16, puncture_degree=3, method=1, max_iter=20, parallel=8,
+                                       snr_begin=3.0, snr_step=1.0, snr_stop=4.0, constellation="BPSK", min_sim_cycle=500)),
+    # CRC-16 and CRC-24 (Comm.cpp:506-636); the reference generates with one CRC-24 polynomial and checks with another (SURVEY
+    # hazard 1): the undetected-error column of the crcLen 24 profile holds what that yields -- reproduced, not repaired.
+    "ems_u128_crc16": ("O2", dict(gfq=256, code=U128_256, method=2, max_iter=50, parallel=8, ems_nm=16, ems_nc=3, crc_len=16,
+                                  snr_begin=1.5, snr_step=0.5, snr_stop=2.0, constellation="BPSK", min_sim_cycle=120)),
+    "ems_u128_crc24": ("O2", dict(gfq=256, code=U128_256, method=2, max_iter=50, parallel=8, ems_nm=16, ems_nc=3, crc_len=24,
+                                  snr_begin=1.5, snr_step=0.5, snr_stop=2.0, constellation="BPSK", min_sim_cycle=120)),
 }
 
 
