@@ -23,6 +23,13 @@
 #include "nbl_fastmath.h"
 #include "nbl_kernels.h"
 
+// section marks for a static instruction budget of the ISA (-DNBL_EMS_MARKS: a comment line per mark, nothing else changes)
+#ifdef NBL_EMS_MARKS
+#define BPMARK(i) asm volatile("; NBLMARK " #i)
+#else
+#define BPMARK(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int Q = 256;
@@ -109,10 +116,17 @@ __device__ __forceinline__ ConvAcc conv_core(const XVec &A, const XVec &B, const
 		s.Bm23[lane] = make_double2(ldexp(B.m[2], B.e[2] + SH), ldexp(B.m[3], B.e[3] + SH));
 		__syncthreads();
 		double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
+		// addresses by hand: the broadcast operand advances by immediate offsets inside a trip of four chunks, the gathered
+		// operand's chunk is one XOR of the lane's byte offset with a scalar (hipcc spends 2.5 vector instructions per chunk on
+		// (lane ^ g) << 4 and on the broadcast address otherwise: 640 of the kernel's 9.7 k per check)
+		const char *const Ab = (const char *)s.Am01, *const Bb = (const char *)s.Bm01;
+		int lane16 = lane << 4;
+		asm("" : "+v"(lane16)); // (opaque: hipcc would re-associate the XOR below into (lane ^ g) << 4, two instructions per chunk)
+#pragma unroll 4
 		for (int g = 0; g < 64; g++) {
-			const double2 a01 = s.Am01[g], a23 = s.Am23[g];
-			const double2 b01 = s.Bm01[lane ^ g], b23 = s.Bm23[lane ^ g];
+			const int bo = lane16 ^ (g << 4);
+			const double2 a01 = *(const double2 *)(Ab + (g << 4)), a23 = *(const double2 *)(Ab + 1024 + (g << 4));
+			const double2 b01 = *(const double2 *)(Bb + bo), b23 = *(const double2 *)(Bb + 1024 + bo);
 			const double a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y};
 #pragma unroll
 			for (int j = 0; j < 4; j++)
@@ -245,11 +259,15 @@ __device__ __forceinline__ bool lse_conv_pair(const XVec &A, const XVec &B1, con
 	Cm23[lane] = make_double2(ldexp(B2.m[2], B2.e[2] + SH), ldexp(B2.m[3], B2.e[3] + SH));
 	__syncthreads();
 	double acc1[4] = {0.0, 0.0, 0.0, 0.0}, acc2[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
+	const char *const Ab = (const char *)s.Am01, *const Bb = (const char *)s.Bm01, *const Cb = (const char *)Cm01;
+	int lane16 = lane << 4;
+	asm("" : "+v"(lane16));
+#pragma unroll 4
 	for (int g = 0; g < 64; g++) {
-		const double2 a01 = s.Am01[g], a23 = s.Am23[g];
-		const double2 b01 = s.Bm01[lane ^ g], b23 = s.Bm23[lane ^ g];
-		const double2 c01 = Cm01[lane ^ g], c23 = Cm23[lane ^ g];
+		const int bo = lane16 ^ (g << 4); // (addresses by hand, as in conv_core)
+		const double2 a01 = *(const double2 *)(Ab + (g << 4)), a23 = *(const double2 *)(Ab + 1024 + (g << 4));
+		const double2 b01 = *(const double2 *)(Bb + bo), b23 = *(const double2 *)(Bb + 1024 + bo);
+		const double2 c01 = *(const double2 *)(Cb + bo), c23 = *(const double2 *)(Cb + 1024 + bo);
 		const double a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y}, c[4] = {c01.x, c01.y, c23.x, c23.y};
 #pragma unroll
 		for (int j = 0; j < 4; j++)
@@ -321,7 +339,7 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 				nv[i] = post[i] - (ownA ? ca : cb);
 			}
 			if (ownA) {
-				const int dec = wave_decide<4>(post, lane, Q);
+				const int dec = wave_decide_keyed<4>(post, lane, Q);
 				if (lane == 0) w.dec[(size_t)b * g.N + n] = dec;
 				if (w.post) {
 #pragma unroll
@@ -337,16 +355,16 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 				double ov[4];
 #pragma unroll
 				for (int i = 0; i < 4; i++) ov[i] = Vd[lane + 64 * i];
-				before = wave_decide<4>(ov, lane, Q);
+				before = wave_decide_keyed<4>(ov, lane, Q);
 			} else before = w.edge_dec[(size_t)b * g.E + e];
-			int after = wave_decide<4>(nv, lane, Q);
+			int after = wave_decide_keyed<4>(nv, lane, Q);
 			if (before != after) {
 #pragma unroll
 				for (int i = 0; i < 4; i++) nv[i] = __dadd_rn(__dmul_rn(r.damp_old, Vd[lane + 64 * i]), __dmul_rn(r.damp_new, nv[i]));
 				double t[4];
 #pragma unroll
 				for (int i = 0; i < 4; i++) t[i] = (lane + 64 * i == 0) ? 0.0 : nv[i];
-				after = wave_decide<4>(t, lane, Q);
+				after = wave_decide_keyed<4>(t, lane, Q);
 			}
 			if (lane == 0) w.edge_dec[(size_t)b * g.E + e] = after;
 #pragma unroll
@@ -359,6 +377,7 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 		}
 	}
 	__syncthreads();
+	BPMARK(0);
 	XVec p[4];
 #pragma unroll
 	for (int d = 0; d < 4; d++) {
@@ -368,6 +387,7 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 		p[d] = to_xvec(L, lane);
 	}
 	__syncthreads();
+	BPMARK(1);
 
 	Lds s;
 	s.Am01 = (double2 *)smem;
@@ -394,9 +414,13 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 	double o[4];
 	// forward: F2 = p0 [+] p1, F3 = F2 [+] p2 = output 3 (A2 == 0 case, :761-764); output 2 = F2 [+] p3
 	{
-		const XVec F2 = conv_xvec(conv_core(p[0], p[1], s, lane, w.stamps));
+		const ConvAcc cF2 = conv_core(p[0], p[1], s, lane, w.stamps);
+		BPMARK(2);
+		const XVec F2 = conv_xvec(cF2);
+		BPMARK(3);
 		double o2[4];
 		if (lse_conv_pair(F2, p[2], p[3], o, o2, s, lane, w.stamps)) {
+			BPMARK(4);
 			emit(o, 3);
 			emit(o2, 2);
 		} else {
@@ -406,6 +430,7 @@ __global__ __launch_bounds__(64, 3) void cn_bp_q256_dc4_kernel(NblGraphDev g, Nb
 			emit(o, 2);
 		}
 	}
+	BPMARK(5);
 	// backward: R1 = p3 [+] p2, R0 = R1 [+] p1 = output 0 (A1 == 0 case, :757-760); output 1 = p0 [+] R1
 	{
 		const XVec R1 = conv_xvec(conv_core(p[3], p[2], s, lane, w.stamps));

@@ -8,8 +8,8 @@
 //     dynamic-programme state of those four check sums live in registers;
 //   * layer 1 is a per-lane minimum (layer 0 is the constant {0 at check sum 0}); layers 2 and 3 gather the 24-byte predecessor
 //     record S[s ^ q] from LDS: for the lane's four symbols that is one address (lane ^ q) XOR-ed with the four plane offsets;
-//   * LDS per wave: one 12.2 KB region used in phases (trellis while it is built and again in the output stage, predecessor
-//     records + ONE column's candidate list during the programme, two output vectors at a time) against 51 KB of the general
+//   * LDS per wave: one 10 KB region used in phases (trellis while it is built and again in the output stage, predecessor
+//     records + ONE column's candidate list during the programme, one output vector at a time) against 51 KB of the general
 //     kernel, which runs less than one wave per SIMD at q = 256.
 // FUSED = true additionally runs the variable-node pass of the iteration for the four incoming edges (dv = 2 codes), exactly
 // as nbl_cn_tems64.hip does.
@@ -23,14 +23,14 @@ constexpr int Q = 256, P = 8, DC = 4, NS = 4;
 
 struct __attribute__((aligned(16))) Cand { double u; int q16; unsigned dig; }; // cost, symbol << 4, symbol << digit shift
 
-// smaller cost wins, equal cost: smaller path code (= earlier in the reference's enumeration order)
+// smaller cost wins, equal cost: smaller path code (= earlier in the reference's enumeration order): the lexicographic
+// comparison as mask arithmetic (three compares, the AND / OR on the scalar unit), then one select for the code; the cost
+// itself is the plain minimum either way (as in nbl_cn_tems64.hip: 5 vector instructions per relaxation instead of 8)
 __device__ __forceinline__ void relax(double &bv, unsigned &bc, double val, unsigned code)
 {
-	const bool lt = val < bv;
-	bv = lt ? val : bv;
-	bc = lt ? code : bc;
-	const unsigned cm = code < bc ? code : bc;
-	bc = (val == bv) ? cm : bc;
+	const bool take = (val < bv) | ((val == bv) & (code < bc));
+	bc = take ? code : bc;
+	bv = __builtin_fmin(bv, val);
 }
 
 __device__ __forceinline__ double pick(const double (&u)[DC], int k)
@@ -43,16 +43,19 @@ __device__ __forceinline__ double pick(const double (&u)[DC], int k)
 template <bool FUSED, int NC>
 __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
-	// One 12.2 KB region, used in two phases (three waves per SIMD instead of the 1.75 that 20 KB would allow):
-	//   programme:  predecessor records Sv | Sc (8 KB) + the candidate list of the current column (4.1 KB)
-	//   before / after it:  the trellis dU (8 KB, rebuilt from registers for the output stage) + two output vectors Lc (4 KB)
-	__shared__ __attribute__((aligned(16))) char lds[2 * Q * 16 + (Q + 4) * 16];
+	// One 10 KB region, used in two phases (sixteen waves per CU = four per SIMD; the register count allows as many):
+	//   programme:  predecessor records Sv (4 KB: 16-byte cost pairs) | Sc (2 KB: 8-byte code pairs) + the candidate list of the
+	//               current column (4 KB: at most 255 candidates, padded to a multiple of four)
+	//   before / after it:  the trellis dU (8 KB, rebuilt from registers for the output stage) + one output vector Lc (2 KB)
+	// Every record is read with the stride of its own size (16-byte costs, 8-byte codes), so a gather touches every LDS bank
+	// once: the 8-byte codes used to sit in 16-byte slots, and their reads at a 16-byte stride reached only half of the banks.
+	__shared__ __attribute__((aligned(16))) char lds[Q * 16 + Q * 8 + Q * 16];
 	char *Sraw = lds;                                      // predecessor records
 	double2 *Sv = (double2 *)Sraw;                         // [Q] cost of layers 1, 2 of every check sum before the current column
-	uint4 *Sc = (uint4 *)(Sraw + Q * 16);                  // [Q] their path codes (x, y)
-	Cand *cl = (Cand *)(lds + 2 * Q * 16);                 // [Q + 4] deviation candidates of the current column
+	uint2 *Sc = (uint2 *)(Sraw + Q * 16);                  // [Q] their path codes (x, y)
+	Cand *cl = (Cand *)(lds + Q * 16 + Q * 8);             // [Q] deviation candidates of the current column
 	double (*dU)[Q] = (double (*)[Q])lds;                  // [DC][Q] delta-domain trellis (:1814-1834)
-	double (*Lc)[Q] = (double (*)[Q])(lds + DC * Q * 8);   // [2][Q] extrinsic minima of two output edges at a time (:1075-1102)
+	double *Lc = (double *)(lds + DC * Q * 8);             // [Q] extrinsic minima of one output edge at a time (:1075-1102)
 
 	const int lane = lane_id();
 	const NblXcdSlot xs = nbl_xcd_slot(g.M); // all checks of a codeword on one XCD (nbl_device.h)
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 		for (int i = 0; i < NS; i++) {
 			const int s = lane + 64 * i;
 			Sv[s] = make_double2(st[i].v1, st[i].v2);
-			Sc[s] = make_uint4(st[i].c1, st[i].c2, 0u, 0u);
+			Sc[s] = make_uint2(st[i].c1, st[i].c2);
 			const bool c = ((mask[i] >> d) & 1) && s > 0;
 			const uint64_t bal = __ballot(c);
 			if (c) {
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 					for (int i = 0; i < NS; i++) {
 						const int off = A ^ (i << 10);
 						const double2 sv = *(const double2 *)(Sraw + off);
-						const uint2 sc = *(const uint2 *)(Sraw + Q * 16 + off);
+						const uint2 sc = *(const uint2 *)(Sraw + Q * 16 + (off >> 1));
 						relax(st[i].v2, st[i].c2, sv.x + e[t].u, sc.x + e[t].dig);
 						if (d >= 2 && nc >= 3) relax(st[i].v3, st[i].c3, sv.y + e[t].u, sc.y + e[t].dig);
 					}
@@ -236,49 +239,42 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 		if (nc >= 3 && (st[i].v3 < dW[i] || (st[i].v3 == dW[i] && st[i].c3 < eta[i]))) { dW[i] = st[i].v3; eta[i] = st[i].c3; }
 	}
 
-	// ---- 4. outputs, two edges at a time (the trellis goes back into the region: the last barrier above has passed) ---------
+	// ---- 4. outputs, one edge at a time (the trellis goes back into the region: the last barrier above has passed) ----------
 #pragma unroll
 	for (int d = 0; d < DC; d++)
 #pragma unroll
 		for (int i = 0; i < NS; i++) dU[d][lane + 64 * i] = u[i][d];
 #pragma unroll
-	for (int h = 0; h < DC; h += 2) {
+	for (int d = 0; d < DC; d++) {
 #pragma unroll
-		for (int d = h; d < h + 2; d++)
-#pragma unroll
-			for (int i = 0; i < NS; i++) Lc[d - h][lane + 64 * i] = NBL_DBL_MAX;
+		for (int i = 0; i < NS; i++) Lc[lane + 64 * i] = NBL_DBL_MAX;
 		__syncthreads();
 #pragma unroll
-		for (int d = h; d < h + 2; d++)
-#pragma unroll
-			for (int i = 0; i < NS; i++) {
-				const int s = lane + 64 * i;
-				const int dev = (int)((eta[i] >> (P * (DC - 1 - d))) & (Q - 1));
-				const double cand = dW[i] - dU[d][dev]; // :1088
-				__hip_atomic_fetch_min(&Lc[d - h][s ^ dev], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			}
+		for (int i = 0; i < NS; i++) {
+			const int s = lane + 64 * i;
+			const int dev = (int)((eta[i] >> (P * (DC - 1 - d))) & (Q - 1));
+			const double cand = dW[i] - dU[d][dev]; // :1088
+			__hip_atomic_fetch_min(&Lc[s ^ dev], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
 		__syncthreads();
 #pragma unroll
-		for (int d = h; d < h + 2; d++)
-#pragma unroll
-			for (int i = 0; i < NS; i++) {
-				const int s = lane + 64 * i;
-				if (Lc[d - h][s] == NBL_DBL_MAX) Lc[d - h][s] = (d == o0[i]) ? pick(u[i], o1[i]) : pick(u[i], o0[i]); // never reached (:1095-1102)
-			}
+		for (int i = 0; i < NS; i++) {
+			const int s = lane + 64 * i;
+			if (Lc[s] == NBL_DBL_MAX) Lc[s] = (d == o0[i]) ? pick(u[i], o1[i]) : pick(u[i], o0[i]); // never reached (:1095-1102)
+		}
 		__syncthreads();
-#pragma unroll
-		for (int d = h; d < h + 2; d++) {
+		{
 			// delta domain -> LLR, un-permute by h (:1105-1127)
 			const int bsyn = syn ^ beta[d];
-			const double L0 = -1.0 * Lc[d - h][bsyn];
+			const double L0 = -1.0 * Lc[bsyn];
 #pragma unroll
 			for (int i = 0; i < NS; i++) {
 				const int a = lane + 64 * i;
 				const int e = mh[d].at_slot(i) ^ bsyn; // eta with h^-1 (eta ^ bsyn) = a
-				C[(size_t)d * Q + a] = (a == 0) ? 0.0 : shape_llr(-1.0 * Lc[d - h][e] - L0, r.factor, r.offset);
+				C[(size_t)d * Q + a] = (a == 0) ? 0.0 : shape_llr(-1.0 * Lc[e] - L0, r.factor, r.offset);
 			}
 		}
-		__syncthreads(); // Lc is reused by the next pair of edges
+		__syncthreads(); // Lc is reused by the next edge
 	}
 }
 

@@ -184,6 +184,30 @@ template <int NS> __device__ __forceinline__ int wave_decide(const double (&v)[N
 	return mx > 0.0 ? arg : 0;
 }
 
+// The same decision with the reduction on 32-bit keys: a vector without a positive entry decides 0 after one compare (every
+// lane's running maximum is the initial 0.0 then: no reduction at all); otherwise the wave maximum of the order-preserving
+// float keys (one DPP instruction per step instead of five for an FP64 step) names the lane that holds the maximum -- rounding
+// to float is monotone -- and the exact value is read from it; several lanes with the maximal key (equal or nearly equal
+// maxima) fall back to the FP64 reduction.  Same result as wave_decide for every input.
+template <int NS> __device__ __forceinline__ int wave_decide_keyed(const double (&v)[NS], int lane, int q)
+{
+	double best = 0.0;
+#pragma unroll
+	for (int i = 0; i < NS; i++)
+		if (lane + 64 * i < q) best = dmax(best, v[i]);
+	if (!__ballot(best > 0.0)) return 0;
+	const int k = nbl_key32(best), kmax = wave_imax_id(k);
+	const uint64_t c = __ballot(k == kmax);
+	const double mx = (__builtin_popcountll(c) == 1) ? read_lane_f64(best, __builtin_ctzll(c)) : wave_fmax(best);
+	int arg = 0;
+#pragma unroll
+	for (int i = NS - 1; i >= 0; i--) {
+		const uint64_t hit = __ballot(lane + 64 * i < q && v[i] == mx);
+		arg = hit ? 64 * i + __builtin_ctzll(hit) : arg;
+	}
+	return arg; // (mx > 0 here)
+}
+
 // check-to-variable shaping, NBLDPC.cpp:903-916 / 1113-1126
 __device__ __forceinline__ double shape_llr(double y, double factor, double offset)
 {

@@ -44,8 +44,15 @@ NBL_FM double nbl_log_pos(double a)
 	double m = frexp(a, &e);                   // [1/2, 1)
 	if (m < 0.75) { m *= 2.0; e -= 1; }        // [3/4, 3/2)
 	const double f = m - 1.0, d = m + 1.0;
-	// s = f / d by reciprocal + one Newton correction of the quotient (d in [1.75, 2.5])
-	const double r = 1.0 / d;
+	// s = f / d by reciprocal + one Newton correction of the quotient (d in [1.75, 2.5]).  The reciprocal only has to be good to
+	// ~2^-24: the correction squares its error and s_lo below picks up what is left, so the device takes the hardware estimate
+	// (v_rcp_f64, one instruction; an IEEE division is ~11) and the host build -- which exists to MEASURE this routine against
+	// libm, tests/test_ddmath.py -- rounds its reciprocal to float, the worst a conforming estimate may be
+#if defined(__HIP_DEVICE_COMPILE__)
+	const double r = __builtin_amdgcn_rcp(d);
+#else
+	const double r = (double)(float)(1.0 / d);
+#endif
 	double s = f * r;
 	s = fma(fma(-s, d, f), r, s);
 	const double s_lo = fma(-s, d, f) * r;     // what is still missing of the quotient

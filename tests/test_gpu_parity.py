@@ -675,8 +675,12 @@ def test_reference_semantics_at_scale(tmp_path, oracle, ebn0, B, seed):
     """GPU against the LITERAL oracle (bit-identical to the compiled reference, residue included) on waterfall frames of the
     north-star configuration at three Eb/N0 points.  Required: identical convergence flags and iteration counts on every frame,
     identical hard decisions on every frame that converges.  Frames that never converge are chaotic trajectories in which the
-    reference's own order-dependent 1e-13 residue (DESIGN.md section 3) can flip an isolated symbol of the final hard decision;
-    the test bounds it at 4 symbols per point and records what it measured."""
+    reference's own order-dependent 1e-13 residue can flip an isolated symbol of the final hard decision.
+    Measured rate (tools/flip_rate.py, profiles/r03_flip_rate.json: 2688 frames at 0.6 dB, 2044 of them never converging): 5
+    differing symbols in 5 frames -- 2.4e-3 per never-converging frame, 3.8e-5 per symbol, none on a converged frame, flags and
+    iteration counts identical throughout.  On the three fixed inputs of this test the measured number is 0; the inputs are
+    deterministic and the kernel's value is kernel-independent (bit-identical to the canonical oracle), so the gate is the measured
+    value + 1: anything above it is a kernel regression, not the residue."""
     from nbldpc_amd import hostlib
     name = "divsalar.UNBLDPC.512.256.GF.256"
     hostlib.prepare_workdir(str(tmp_path), dict(gfq=256, code=name, method=2, max_iter=50, parallel=B, ems_nm=32, ems_nc=3,
@@ -697,7 +701,7 @@ def test_reference_semantics_at_scale(tmp_path, oracle, ebn0, B, seed):
                                                symbol_diffs=diff, frames_with_diffs=int((out != l_out).any(axis=1).sum())))
     assert np.array_equal(conv, l_conv) and np.array_equal(iters, l_it)
     assert np.array_equal(out[conv == 1], l_out[conv == 1])
-    assert diff <= 4, diff
+    assert diff <= 1, diff  # measured on these inputs: 0
 
 
 @pytest.mark.parametrize("label,code_name,cons,B,ebn0,iters,kw,rm", [
@@ -712,7 +716,7 @@ def test_tems_reference_semantics_at_scale(tmp_path, oracle, label, code_name, c
     NBLDPC.cpp:1892-1944) on waterfall frames, all iterations.  The kernels' dynamic programme keeps the cheaper PREFIX when two
     paths round to the same cost; this test measures whether that ever shows on real-valued LLRs: flags and
     iteration counts must be identical on every frame, hard decisions on every frame that converges; symbol differences on
-    never-converging frames are recorded and bounded."""
+    never-converging frames are recorded and gated at the measured value (0 on all four inputs) + 1."""
     from nbldpc_amd import hostlib
     c = df.codes()[code_name]
     q = c["q"]
@@ -733,7 +737,7 @@ def test_tems_reference_semantics_at_scale(tmp_path, oracle, label, code_name, c
                                                symbol_diffs=diff, frames_with_diffs=int((out != l_out).any(axis=1).sum())))
     assert np.array_equal(conv, l_conv) and np.array_equal(its, l_it)
     assert np.array_equal(out[conv == 1], l_out[conv == 1])
-    assert diff <= 4, diff
+    assert diff <= 1, diff  # measured on these inputs: 0
 
 
 def test_bp_gf256_deep_trajectory_vs_reference():
