@@ -351,6 +351,18 @@ extern "C" nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_m
 			}
 		if ((st = upload(d, toff, &d->g.ems_toff))) return fail_create(d, st, "");
 	}
+	if (d->all_dc4 && d->all_dv2) {
+		std::vector<int> row((size_t)M * 16);
+		for (int m = 0; m < M; m++)
+			for (int j = 0; j < 4; j++) {
+				const int ce = coff[m] + j, n = c_var[ce], e = c_epos[ce], e0 = voff[n];
+				row[(size_t)m * 16 + j] = n;
+				row[(size_t)m * 16 + 4 + j] = v_cpos[e0];
+				row[(size_t)m * 16 + 8 + j] = v_cpos[e0 + 1];
+				row[(size_t)m * 16 + 12 + j] = e | ((e == e0) ? (int)0x80000000 : 0);
+			}
+		if ((st = upload(d, row, &d->g.dv2_row))) return fail_create(d, st, "");
+	}
 	int mindv = maxdv;
 	for (int n = 0; n < N; n++) mindv = code->var_deg[n] < mindv ? code->var_deg[n] : mindv;
 	if (q <= 64 && maxdv <= 3 && mindv >= 2) {

@@ -336,10 +336,12 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		double2 l0[4], l1[4], a0[4], a1[4], b0[4], b1[4];
 		int nvar[4], eidx[4];
 		bool ownA[4];
+		// (one 64-byte row per check holds what the chain c_var / c_epos -> voff -> v_cpos would deliver after three dependent
+		// scalar loads: the first vector load of the wave is issued that much earlier)
+		const int *row = g.dv2_row + (size_t)m * 16;
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
-			const int n = g.c_var[c0 + j], e = g.c_epos[c0 + j], e0 = g.voff[n];
-			const int cpA = g.v_cpos[e0], cpB = g.v_cpos[e0 + 1];
+			const int n = row[j], cpA = row[4 + j], cpB = row[8 + j], e = row[12 + j] & 0x7fffffff;
 			const double2 *pl = (const double2 *)(w.Lch + ((size_t)b * g.N + n) * Q);
 			const double2 *pa = (const double2 *)(Cp + (size_t)cpA * Q);
 			const double2 *pb = (const double2 *)(Cp + (size_t)cpB * Q);
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			b0[j] = pb[lane]; b1[j] = pb[64 + lane];
 #endif
 			nvar[j] = n; eidx[j] = e;
-			ownA[j] = (e == e0); // this check is the variable's first edge
+			ownA[j] = row[12 + j] < 0; // this check is the variable's first edge
 		}
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 
 bool nbl_ems256_applicable(const NblGraphDev &g, bool all_dc4, int nm, int nc)
 {
-	return g.q == 256 && all_dc4 && nc >= 1 && (nm == 8 || nm == 16 || nm == 32) && g.ems_toff != nullptr;
+	return g.q == 256 && all_dc4 && nc >= 1 && (nm == 8 || nm == 16 || nm == 32) && g.ems_toff != nullptr; // (fused: g.dv2_row too, see fused_shape)
 }
 
 size_t nbl_ems256_lds_bytes(int nm) { return 3 * Q * 8 + (size_t)4 * nm * 16; }

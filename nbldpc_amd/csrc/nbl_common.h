@@ -30,6 +30,10 @@ struct NblGraphDev {
 	                    // n's edges in order (third = -1 at degree 2) and, in [3], 1 if e is n's first edge (nbl_cn_small.hip, fused)
 	const unsigned long long *ems_toff; // [E][64] GF(256), all checks of degree 4 only (else NULL): for check-major edge e and lane l the
 	                    // byte offsets 8 * (h_e * a) of a = 2l, 2l+1, 128+2l, 129+2l, 16 bits each (nbl_cn_ems256.hip)
+	const int *dv2_row; // [M][16] every check of degree 4 and every variable of degree 2 only (else NULL): all a fused iteration needs
+	                    // to address the inputs of check m, in ONE 64-byte row: [0..3] variable of edge j, [4..7] c2v slot of that
+	                    // variable's first edge, [8..11] of its second edge, [12..15] variable-major position of edge j, bit 31 set
+	                    // when edge j IS the variable's first edge (one scalar load instead of a chain of four dependent ones)
 };
 
 struct NblWork {

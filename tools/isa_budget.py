@@ -31,7 +31,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "nbldpc_amd", "csrc", "nbl_cn_ems256.hip")
-FLAGS = ["-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-strict-aliasing", "--offload-arch=gfx950", "-x", "hip", "--cuda-device-only", "-S"]
+FLAGS = ["-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-strict-aliasing", "-mllvm", "-enable-pre=false", "--offload-arch=gfx950", "-x", "hip", "--cuda-device-only", "-S"]
 
 # sections: the mark that ENDS them (STAMP(i) sits at the end of section i in the source)
 SECTION_OF_MARK = {0: "load + variable-node pass", 1: "rank 0 (maximum, its symbol, lower bound)", 5: "staging into the check domain + conf(q,1)",
