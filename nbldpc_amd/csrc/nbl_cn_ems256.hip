@@ -644,7 +644,11 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		// field, no address arithmetic).  UN entries per trip, then the remainder one by one (no padding entries)
 		auto body = [&](const ListEnt &en, auto swapped, auto upper) {
 			constexpr bool SW = decltype(swapped)::value, HI = decltype(upper)::value;
+#if NBL_WHATIF == 10 // diagnostic (wrong results): every lane gathers from ONE address (same instructions, one LDS pass per read)
+			const int ad = en.tt & 1008;
+#else
 			const int ad = lane16 ^ en.tt; // (tt holds bits 1..6 of t only)
+#endif
 			double2 ra[NP], rb[NP];
 #pragma unroll
 			for (int p = 0; p < NP; p++) {
