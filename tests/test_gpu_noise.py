@@ -138,3 +138,20 @@ def test_channel_entry_points_edge_cases(tmp_path):
     lib.nbl_rand_advance(st.ctypes.data, 0)
     assert np.array_equal(st, state[0])               # zero draws: unchanged
     dec.close()
+
+
+def test_short_log_and_exp2_on_the_device(tmp_path):
+    """The DEVICE build of nbl_fastmath.h -- its short logarithm takes the hardware reciprocal estimate (v_rcp_f64) where the host
+    build divides -- against this machine's libm on 4 M arguments: at most one ulp, like the host build (tests/test_ddmath.py)."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fastmath_device_check")
+    subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-I", os.path.join(root, "nbldpc_amd", "csrc"),
+                           os.path.join(root, "tests", "fastmath_device_check.hip"), "-o", exe])
+    r = json.loads(subprocess.check_output([exe], text=True))
+    assert r["exp2_worst_ulp"] <= 1.0 and r["log_worst_ulp"] <= 1.0, r
