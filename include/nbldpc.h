@@ -129,7 +129,9 @@ nbl_status nbl_decode_batch_noise(nbl_decoder *dec, const uint8_t *tx_index, con
 /* The same in two phases, for callers that overlap the channel of batch k+1 with the decode of batch k (two host threads):
  * nbl_channel_batch forms the samples of a batch into the decoder's resident buffer `slot` (0 or 1) on a second stream and returns
  * when they are complete; nbl_decode_batch_resident demodulates and decodes what a slot holds.  A channel call and a decode call
- * on DIFFERENT slots may run concurrently; otherwise the handle is single-threaded like every other call. */
+ * on DIFFERENT slots may run concurrently; otherwise the handle is single-threaded like every other call.  The two threads keep
+ * separate error texts (nbl_last_error reports the decode side's, then the channel side's after " | channel: ").
+ * tx_index values must be below mod_order (NBL_ERR_ARG otherwise). */
 nbl_status nbl_channel_batch(nbl_decoder *dec, int32_t slot, const uint8_t *tx_index, const uint32_t *lane_state, double sigma, int32_t B);
 nbl_status nbl_decode_batch_resident(nbl_decoder *dec, int32_t slot, double sigma, int32_t B, int32_t *out_sym, uint8_t *converged,
                                      int32_t *iters);
