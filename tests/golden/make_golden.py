@@ -137,6 +137,8 @@ FER_SETS = {
     # GF(16) 256.128 code from the channel (its bits are not sent; the demodulator gives them LLR 0).
     "ems_gf16_u256_punct3": ("O2", dict(gfq=16, code=U256_16, puncture_degree=3, method=2, max_iter=20, parallel=8, ems_nm=8, ems_nc=3,
                                         snr_begin=3.0, snr_step=1.0, snr_stop=4.0, constellation="BPSK", min_sim_cycle=500)),
+    "tems_gf16_u256_punct3": ("O2", dict(gfq=16, code=U256_16, puncture_degree=3, method=4, max_iter=20, parallel=8, tems_nr=2, tems_nc=3,
+                                         snr_begin=3.0, snr_step=1.0, snr_stop=4.0, constellation="BPSK", min_sim_cycle=500)),
     "bp_gf16_u256_punct3": ("O0", dict(gfq=16, code=U256_16, puncture_degree=3, method=1, max_iter=20, parallel=8,
                                        snr_begin=3.0, snr_step=1.0, snr_stop=4.0, constellation="BPSK", min_sim_cycle=500)),
     # CRC-16 and CRC-24 (Comm.cpp:506-636); the reference generates with one CRC-24 polynomial and checks with another (SURVEY
