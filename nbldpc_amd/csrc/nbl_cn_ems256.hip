@@ -342,7 +342,11 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const int n = row[j], cpA = row[4 + j], cpB = row[8 + j], e = row[12 + j] & 0x7fffffff;
+#if NBL_WHATIF == 11 // diagnostic (wrong results): every wave reads the channel vectors of codewords 0..7 (L2 hits instead of HBM)
+			const double2 *pl = (const double2 *)(w.Lch + ((size_t)(b & 7) * g.N + n) * Q);
+#else
 			const double2 *pl = (const double2 *)(w.Lch + ((size_t)b * g.N + n) * Q);
+#endif
 			const double2 *pa = (const double2 *)(Cp + (size_t)cpA * Q);
 			const double2 *pb = (const double2 *)(Cp + (size_t)cpB * Q);
 #if NBL_WHATIF == 4 // diagnostic (wrong results): no HBM reads, inputs made up from the addresses

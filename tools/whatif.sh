@@ -2,7 +2,8 @@
 # Sensitivity of the headline kernel: diagnostic builds that leave ONE kind of work out (results are wrong on purpose):
 #   make -C nbldpc_amd/csrc OBJDIR=build_w$w XFLAGS=-DNBL_WHATIF=$w OUT=ab/libw$w.so   for w = 1 (no gather LDS reads),
 #   2 (no gather additions), 3 (no pair-convolution atomics), 4 (no HBM reads), 5 / 6 (three / two waves per SIMD),
-#   7 (plain stores instead of the atomics), 10 (every gather read from one address: no LDS bandwidth);
+#   7 (plain stores instead of the atomics), 10 (every gather read from one address: no LDS bandwidth),
+#   11 (channel vectors of codewords 0..7 for every wave: L2 hits instead of HBM first touches);
 # then tools/whatif.sh on the GPU box.  ONE iteration per decode (--iters 1): every variant sees the same inputs -- with more
 # iterations the wrong results of a variant change the data of the later iterations, and the kernel's time depends on the data.
 for rep in 1 2; do
