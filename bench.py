@@ -13,6 +13,8 @@ Rank 0 prints ONE JSON line.  Extra objects:
   roofline      dominant kernel (fused EMS iteration): algorithmic bytes per launch / mean launch time (HIP events on
                 the launch stream inside the timed region) against the 8 TB/s HBM peak; `traffic` / `hbm_actual_GBps` = what
                 the kernel really moves (committed PMC passes), `limiter` = what it waits for
+  other_configs (N = 1 only) BASELINE configs 2, 4 and 5 at fixed iterations, one short pass each AFTER the headline's timed region:
+                codewords/s, ms per launch and the fused kernel's algorithmic-bytes roofline (tools/bench_config.py::run_config)
   cpu_baseline  the compiled reference itself (oracle/_ref, kind "reference") on this host's cores, decode loop only, on a
                 bounded sample of the same workload (rank 0, N=1 only); cpu_baseline_port = the oracle's literal restatement
                 on codewords of the same batch (kind "port"; also the fallback when oracle/_ref is absent)
