@@ -856,10 +856,19 @@ static nbl_status run_channel(nbl_decoder *d, const uint8_t *tx_index, const uin
 	nbl_status s = ensure_noise(d, B, err);
 	if (s) return s;
 	const size_t L = d->dm_L;
-	{ // an index beyond the constellation would read past d_cons in the finish kernel
-		unsigned worst = 0;
-		for (size_t i = 0, n = (size_t)B * L; i < n; i++) worst = tx_index[i] > worst ? tx_index[i] : worst;
-		if ((int)worst >= d->dm_order) { err = "tx_index holds a value >= mod_order"; return NBL_ERR_ARG; }
+	if (d->dm_order < 256) { // an index beyond the constellation would read past d_cons in the finish kernel (8 bytes per step:
+		// the modulation orders are powers of two, so "some byte >= order" is "some bit above the order's bits is set")
+		const size_t n = (size_t)B * L;
+		const uint8_t hi = (uint8_t)~(d->dm_order - 1);
+		uint64_t m8 = 0, any = 0;
+		for (int k = 0; k < 8; k++) m8 = (m8 << 8) | hi;
+		size_t i = 0;
+		for (; i + 8 <= n; i += 8) { uint64_t w8; memcpy(&w8, tx_index + i, 8); any |= w8 & m8; }
+		for (; i < n; i++) any |= (uint64_t)(tx_index[i] & hi);
+		if (any || (d->dm_order & (d->dm_order - 1))) {
+			for (size_t k = 0; k < n; k++)
+				if ((int)tx_index[k] >= d->dm_order) { err = "tx_index holds a value >= mod_order"; return NBL_ERR_ARG; }
+		}
 	}
 	const size_t bytes = (size_t)B * L * 16;
 	if (bytes > *rx_cap) {
