@@ -4,7 +4,7 @@ in ConstructConf, NBLDPC.cpp:1767/1773) change a hard decision?  GPU (canonical 
 (bit-identical to the compiled reference) on never-converging EMS frames of the north-star configuration -- the only frames on
 which a difference has ever been seen -- until at least `want` of them have been decoded.
 
-  python tools/flip_rate.py [want=2000] [ebn0=0.6] [chunk=384] [ems|tems64]   (GPU box: ~20 frames/s of oracle on 16 threads)
+  python tools/flip_rate.py [want=2000] [ebn0=0.6] [chunk=384] [ems|tems64|tems256]   (GPU box: ~20 frames/s of oracle on 16 threads)
 `tems64`: the same for T-EMS nr=2 nc=3 on the BDS GF(64) code over 64-QAM (BASELINE config 4), where the kernels' dynamic programme
 could in principle differ from the reference in the PATH it keeps among equal-cost ones.
 Writes gpurun_out/r03_flip_rate[_tems64].json; the committed copies are under profiles/."""
@@ -29,18 +29,20 @@ def main():
     ebn0 = float(sys.argv[2]) if len(sys.argv) > 2 else 0.6
     chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 384
     which = sys.argv[4] if len(sys.argv) > 4 else "ems"
-    tems = which == "tems64"
-    name = "BDS.576.288.GF.64" if tems else "divsalar.UNBLDPC.512.256.GF.256"
-    cons = "GRAY_64QAM" if tems else "BPSK"
+    tems = which in ("tems64", "tems256")
+    t256 = which == "tems256"   # T-EMS on the north-star code: the literal enumeration costs ~3 core-seconds per iteration and frame -> 12 iterations
+    iters = 12 if t256 else 50
+    name = "BDS.576.288.GF.64" if which == "tems64" else "divsalar.UNBLDPC.512.256.GF.256"
+    cons = "GRAY_64QAM" if which == "tems64" else "BPSK"
     po.build()
     c = df.codes()[name]
     N, M, q, ev, ec, eh = df.code_edges(name)
     ocode, ogf = po.Code(edges=(N, M, q, ev, ec, eh)), po.GF(q)
     code = nb.Code(name)
     if tems:
-        mk = lambda: po.Decoder(ocode, ogf, po.TEMS, 50, po.LITERAL, tems_nr=2, tems_nc=3)  # noqa: E731
-        dec = nb.Decoder(code, nb.METHOD_TEMS, 50, tems_nr=2, tems_nc=3, poll_every=5)
-        prof = dict(gfq=64, code=name, method=4, max_iter=50, tems_nr=2, tems_nc=3, nqam=64, constellation=cons, random_msg=0)
+        mk = lambda: po.Decoder(ocode, ogf, po.TEMS, iters, po.LITERAL, tems_nr=2, tems_nc=3)  # noqa: E731
+        dec = nb.Decoder(code, nb.METHOD_TEMS, iters, tems_nr=2, tems_nc=3, poll_every=4)
+        prof = dict(gfq=q, code=name, method=4, max_iter=iters, tems_nr=2, tems_nc=3, nqam=(2 if t256 else 64), constellation=cons, random_msg=(1 if t256 else 0))
     else:
         mk = lambda: po.Decoder(ocode, ogf, po.EMS, 50, po.LITERAL, ems_nm=32, ems_nc=3)  # noqa: E731
         dec = nb.Decoder(code, nb.METHOD_EMS, 50, ems_nm=32, ems_nc=3, poll_every=5)
@@ -68,12 +70,12 @@ def main():
         seed += 1
         print(f"[{time.time() - t0:6.0f}s] {ch}", flush=True)
     dec.close()
-    res = dict(config=f"{name}, {'T-EMS nr=2 nc=3' if tems else 'EMS nm=32 nc=3'}, 50 iterations, {cons}, Eb/N0 {ebn0} dB; GPU (canonical) vs oracle LITERAL (= compiled reference)",
+    res = dict(config=f"{name}, {'T-EMS nr=2 nc=3' if tems else 'EMS nm=32 nc=3'}, {iters} iterations, {cons}, Eb/N0 {ebn0} dB; GPU (canonical) vs oracle LITERAL (= compiled reference)",
                total=tot, worst_chunk_symbol_diffs=max(ch["symbol_diffs"] for ch in chunks), chunk_size=chunk, chunks=chunks,
                symbol_flip_rate_on_never_converging_frames=tot["symbol_diffs"] / max(1, tot["symbols_compared_on_never_converging_frames"]),
                frame_rate_on_never_converging_frames=tot["frames_with_diffs"] / max(1, tot["never_converged"]))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r03_flip_rate_tems64.json" if tems else "r03_flip_rate.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", f"r03_flip_rate_{which}.json" if tems else "r03_flip_rate.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if k != "chunks"}, indent=1))
 
 
