@@ -31,7 +31,7 @@ def main():
     which = sys.argv[4] if len(sys.argv) > 4 else "ems"
     tems = which in ("tems64", "tems256")
     t256 = which == "tems256"   # T-EMS on the north-star code: the literal enumeration costs ~3 core-seconds per iteration and frame -> 12 iterations
-    iters = 12 if t256 else 50
+    n_it = 12 if t256 else 50
     name = "BDS.576.288.GF.64" if which == "tems64" else "divsalar.UNBLDPC.512.256.GF.256"
     cons = "GRAY_64QAM" if which == "tems64" else "BPSK"
     po.build()
@@ -40,9 +40,9 @@ def main():
     ocode, ogf = po.Code(edges=(N, M, q, ev, ec, eh)), po.GF(q)
     code = nb.Code(name)
     if tems:
-        mk = lambda: po.Decoder(ocode, ogf, po.TEMS, iters, po.LITERAL, tems_nr=2, tems_nc=3)  # noqa: E731
-        dec = nb.Decoder(code, nb.METHOD_TEMS, iters, tems_nr=2, tems_nc=3, poll_every=4)
-        prof = dict(gfq=q, code=name, method=4, max_iter=iters, tems_nr=2, tems_nc=3, nqam=(2 if t256 else 64), constellation=cons, random_msg=(1 if t256 else 0))
+        mk = lambda: po.Decoder(ocode, ogf, po.TEMS, n_it, po.LITERAL, tems_nr=2, tems_nc=3)  # noqa: E731
+        dec = nb.Decoder(code, nb.METHOD_TEMS, n_it, tems_nr=2, tems_nc=3, poll_every=4)
+        prof = dict(gfq=q, code=name, method=4, max_iter=n_it, tems_nr=2, tems_nc=3, nqam=(2 if t256 else 64), constellation=cons, random_msg=(1 if t256 else 0))
     else:
         mk = lambda: po.Decoder(ocode, ogf, po.EMS, 50, po.LITERAL, ems_nm=32, ems_nc=3)  # noqa: E731
         dec = nb.Decoder(code, nb.METHOD_EMS, 50, ems_nm=32, ems_nc=3, poll_every=5)
@@ -70,7 +70,7 @@ def main():
         seed += 1
         print(f"[{time.time() - t0:6.0f}s] {ch}", flush=True)
     dec.close()
-    res = dict(config=f"{name}, {'T-EMS nr=2 nc=3' if tems else 'EMS nm=32 nc=3'}, {iters} iterations, {cons}, Eb/N0 {ebn0} dB; GPU (canonical) vs oracle LITERAL (= compiled reference)",
+    res = dict(config=f"{name}, {'T-EMS nr=2 nc=3' if tems else 'EMS nm=32 nc=3'}, {n_it} iterations, {cons}, Eb/N0 {ebn0} dB; GPU (canonical) vs oracle LITERAL (= compiled reference)",
                total=tot, worst_chunk_symbol_diffs=max(ch["symbol_diffs"] for ch in chunks), chunk_size=chunk, chunks=chunks,
                symbol_flip_rate_on_never_converging_frames=tot["symbol_diffs"] / max(1, tot["symbols_compared_on_never_converging_frames"]),
                frame_rate_on_never_converging_frames=tot["frames_with_diffs"] / max(1, tot["never_converged"]))
