@@ -1,5 +1,5 @@
 // nbldpc_amd/csrc/nbl_cn_ems256.hip -- EMS check node specialised for the headline shape:
-//   GF(256), every check of degree 4, any nc >= 1, nm in {8,16,32}.
+//   GF(256), every check of degree 4, any nc >= 1, nm in {8,16,32,64}.
 // (BASELINE configs 2 and 3: divsalar.UNBLDPC.{128.64,512.256}.GF.256, EMS nm=16/32.)
 //
 // Same arithmetic as cn_ems_kernel<256> (nbl_kernels.hip) -- the generic kernel is the readable statement of the
@@ -259,7 +259,7 @@ __device__ __forceinline__ void finish_members(SelState &s, int nm, uint64_t (&m
 template <int NM, bool FUSED, int NC>
 __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
-	constexpr int LOGNM = (NM == 8) ? 3 : (NM == 16) ? 4 : 5;
+	constexpr int LOGNM = (NM == 8) ? 3 : (NM == 16) ? 4 : (NM == 32) ? 5 : 6;
 	// static LDS: its base is a compile-time constant, so computed addresses fold into the ds_* offset fields (with `extern
 	// __shared__` every computed address pays a v_add with the link-time base)
 #if NBL_WHATIF == 5   // diagnostic: three waves per SIMD (13 KB of LDS per wave)
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 
 bool nbl_ems256_applicable(const NblGraphDev &g, bool all_dc4, int nm, int nc)
 {
-	return g.q == 256 && all_dc4 && nc >= 1 && (nm == 8 || nm == 16 || nm == 32) && g.ems_toff != nullptr; // (fused: g.dv2_row too, see fused_shape)
+	return g.q == 256 && all_dc4 && nc >= 1 && (nm == 8 || nm == 16 || nm == 32 || nm == 64) && g.ems_toff != nullptr; // (fused: g.dv2_row too, see fused_shape)
 }
 
 size_t nbl_ems256_lds_bytes(int nm) { return 3 * Q * 8 + (size_t)4 * nm * 16; }
@@ -826,6 +826,7 @@ hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const Nb
 		case 8: launch_nc<8, true>(r.nc, grid, block, st, g, w, r); break;
 		case 16: launch_nc<16, true>(r.nc, grid, block, st, g, w, r); break;
 		case 32: launch_nc<32, true>(r.nc, grid, block, st, g, w, r); break;
+		case 64: launch_nc<64, true>(r.nc, grid, block, st, g, w, r); break;
 		default: return hipErrorInvalidValue;
 		}
 	} else {
@@ -833,6 +834,7 @@ hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const Nb
 		case 8: launch_nc<8, false>(r.nc, grid, block, st, g, w, r); break;
 		case 16: launch_nc<16, false>(r.nc, grid, block, st, g, w, r); break;
 		case 32: launch_nc<32, false>(r.nc, grid, block, st, g, w, r); break;
+		case 64: launch_nc<64, false>(r.nc, grid, block, st, g, w, r); break;
 		default: return hipErrorInvalidValue;
 		}
 	}
