@@ -745,7 +745,7 @@ def test_bp_gf256_deep_trajectory_vs_reference():
     (16 frames at 2.8 dB, tests/golden/cfg5_bp_c512_deep.npz): the wide mantissa/exponent path of the kernel is what runs here.
     Zero-syndrome flags of every frame and hard decisions of every converged frame must equal the reference's; the reference
     accumulates in 80-bit long double, the kernel in FP64, so never-converging (chaotic) frames may differ in a few symbols
-    (recorded, bounded), and the message state after 10 iterations must agree to 1e-7 relative to the largest magnitude."""
+    (recorded; gated at the measured value, 0, + 1), and the message state after 10 iterations must agree to 1e-7 relative to the largest magnitude."""
     g, meta = load_golden("cfg5_bp_c512_deep")
     p, kw = meta["profile"], decoder_kwargs(meta["profile"])
     code = nb.Code(meta["code"])
@@ -762,7 +762,7 @@ def test_bp_gf256_deep_trajectory_vs_reference():
                                                                         flag_mismatches=int((conv.astype(bool) != ref_ok).sum()), symbol_diffs=diff))
             assert np.array_equal(conv.astype(bool), ref_ok), (generic, int(it))
             assert np.array_equal(out[ref_ok], g["out"][k][ref_ok]), (generic, int(it))
-            assert diff <= 8, (generic, int(it), diff)
+            assert diff <= 1, (generic, int(it), diff)  # measured with every kernel of rounds 2 and 3: 0 (profiles/r03_parity_stats.json)
         dec = nb.Decoder(code, p["method"], int(g["state_iters"][0]), **kw)
         _force_generic(dec, generic)
         dec.record_state(True)
@@ -804,7 +804,9 @@ def test_other_methods_frame_by_frame_at_scale(tmp_path, oracle, name, code_name
     if method == 4:
         assert np.array_equal(out, o_out)
     else:
-        assert int((out != o_out).sum()) <= 4
+        nd = int((out != o_out).sum())
+        _record_stat(f"bp_fp64_restatement_{name}", dict(frames=B, converged=int(conv.sum()), symbol_diffs=nd))
+        assert nd <= 1, nd  # measured: 0 (never-converging frames against the oracle's FP64 restatement; exp / log differ in the last bit)
     assert 0.05 < conv.mean() <= 1.0
 
 
