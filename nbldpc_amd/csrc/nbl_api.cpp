@@ -139,7 +139,7 @@ static void free_workspace(nbl_decoder *d)
 }
 
 // Shapes whose whole iteration is ONE launch (variable-node pass recomputed inside the check-node kernel, c2v double-buffered):
-// (2,4)-regular codes, EMS over GF(256) with nm in {8,16,32}, T-EMS over GF(64) and GF(256), log-QSPA over GF(256).
+// (2,4)-regular codes, EMS over GF(256) with nm <= 64, T-EMS over GF(64) and GF(256), log-QSPA over GF(256).
 static bool small_enabled()
 {
 	static const bool on = !getenv("NBL_NO_SMALL"); // A/B measurements: the one-check-per-wave kernels on small fields
@@ -299,7 +299,7 @@ extern "C" nbl_status nbl_create(const nbl_code_desc *code, const uint16_t *gf_m
 	if (params->method == NBL_METHOD_EMS) {
 		const int layers = (params->ems_nc >= maxdc - 1) ? 1 : params->ems_nc + 1;
 		const size_t lds = ((size_t)maxdc * q + (2 * (size_t)layers + 1) * q + (size_t)maxdc * params->ems_nm) * 8 + (size_t)maxdc * params->ems_nm * 4 + 16;
-		const bool special = q == 256 && maxdc == 4 && params->ems_nc >= 1 && (params->ems_nm == 8 || params->ems_nm == 16 || params->ems_nm == 32 || params->ems_nm == 64);
+		const bool special = q == 256 && maxdc == 4 && params->ems_nc >= 1 && params->ems_nm <= 64;
 		if (!special && lds > 160 * 1024)
 			return fail_create(nullptr, NBL_ERR_UNSUPPORTED, "EMS: this (q, check degree, nm, nc) needs more than the 160 KB of LDS one wave can have");
 	}

@@ -1,5 +1,5 @@
 // nbldpc_amd/csrc/nbl_cn_ems256.hip -- EMS check node specialised for the headline shape:
-//   GF(256), every check of degree 4, any nc >= 1, nm in {8,16,32,64}.
+//   GF(256), every check of degree 4, any nc >= 1, any nm <= 64 (8, 16, 32, 64 as compile-time constants).
 // (BASELINE configs 2 and 3: divsalar.UNBLDPC.{128.64,512.256}.GF.256, EMS nm=16/32.)
 //
 // Same arithmetic as cn_ems_kernel<256> (nbl_kernels.hip) -- the generic kernel is the readable statement of the
@@ -256,9 +256,15 @@ __device__ __forceinline__ void finish_members(SelState &s, int nm, uint64_t (&m
 // edge writes its hard decision.  c2v is double-buffered (w.c2v_prev -> w.c2v) because the schedule is flooding.
 // NC = min(nc, 3): 3 = no deviation counting needed (every other edge may deviate); 2 = at least one of the three other
 // edges stays at rank 0; 1 = conf(nm,1) is a subset of conf(q,1), nothing beyond the closed form is needed.
-template <int NM, bool FUSED, int NC>
+// NMT > 0: nm = NMT, a compile-time constant (8, 16, 32, 64).  NMT < 0: any other nm, given at run time, on the layout of the next
+// power of two -NMT -- the unused tail of every list is pre-filled with entries of value -inf, which no maximum can pick up:
+// the pair scatters run over them (cost of the larger layout), the gathers stop at nm.
+template <int NMT, bool FUSED, int NC>
 __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
+	constexpr int NM = NMT < 0 ? -NMT : NMT;
+	constexpr bool VARNM = NMT < 0;
+	const int nmr = VARNM ? r.nm : NM; // the nm of the selection (the list layout and the loops over it use NM)
 	constexpr int LOGNM = (NM == 8) ? 3 : (NM == 16) ? 4 : (NM == 32) ? 5 : 6;
 	// static LDS: its base is a compile-time constant, so computed addresses fold into the ds_* offset fields (with `extern
 	// __shared__` every computed address pays a v_add with the link-time base)
@@ -525,23 +531,33 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		int2 tt2[4];
 #pragma unroll
 		for (int i = 0; i < 4; i++) { tt2[i].x = sym_of(lane, i) << 3; tt2[i].y = (sym_of(lane, i) & 0x7E) << 3; }
+		if (VARNM) { // list entries beyond the nm selected ones: value -inf, pairwise different symbols (a scatter of several lanes
+			// to ONE address is serialised by the LDS)
+			WSYNC();
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				lstv[j * NM + (lane & (NM - 1))] = NBL_NEG_INF;
+				lstt[j * NM + (lane & (NM - 1))] = make_int2((lane & (NM - 1)) << 3, 0);
+			}
+			WSYNC();
+		}
 		// per edge: locate the cut bucket, settle the members, compact them into the list image
 		// [even-symbol group | odd-symbol group]
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const int tot = hc[0][j] + hc[1][j] + hc[2][j] + hc[3][j];
 			const int cum = wave_scan_add(tot);
-			const uint64_t reach = __ballot(cum >= NM);
+			const uint64_t reach = __ballot(cum >= nmr);
 			const int lstar = reach ? __builtin_ctzll(reach) : 63;
 			// the cut lane's four bucket counts and its running total: which of its buckets holds the nm-th entry is scalar work
 			const int cl = __builtin_amdgcn_readlane(cum, lstar);
 			const int q1 = __builtin_amdgcn_readlane(hc[1][j], lstar),
 			          q2 = __builtin_amdgcn_readlane(hc[2][j], lstar), q3 = __builtin_amdgcn_readlane(hc[3][j], lstar);
 			const int s0 = cl - q3 - q2 - q1, s1 = cl - q3 - q2, s2 = cl - q3;
-			const int bsel = (s0 >= NM) ? 0 : (s1 >= NM) ? 1 : (s2 >= NM) ? 2 : 3;
-			const int upto = (s0 >= NM) ? s0 : (s1 >= NM) ? s1 : (s2 >= NM) ? s2 : cl; // entries up to and including the cut bucket
+			const int bsel = (s0 >= nmr) ? 0 : (s1 >= nmr) ? 1 : (s2 >= nmr) ? 2 : 3;
+			const int upto = (s0 >= nmr) ? s0 : (s1 >= nmr) ? s1 : (s2 >= nmr) ? s2 : cl; // entries up to and including the cut bucket
 			const int bstar = 4 * lstar + bsel;
-			const bool exact = reach && upto == NM; // the cut bucket ends exactly at the nm-th entry
+			const bool exact = reach && upto == nmr; // the cut bucket ends exactly at the nm-th entry
 			uint64_t member[4];
 			if (exact) {
 #pragma unroll
@@ -554,10 +570,10 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 				for (int i = 0; i < 4; i++) { ss.cand[i] = reach ? __ballot(bk[j][i] == bstar) : ~0ull; ss.gt[i] = ss.eq[i] = 0; }
 				ss.done = 0;
 				for (int guard = 0; guard < 300 && !ss.done; guard++) {
-					select_step(v[j], NM, ss);
+					select_step(v[j], nmr, ss);
 					STAMP_COUNT(9);
 				}
-				finish_members(ss, NM, member, g.c_hinv[c0 + j], g.poly, lane);
+				finish_members(ss, nmr, member, g.c_hinv[c0 + j], g.poly, lane);
 			}
 			// compaction straight from the (wave-uniform) member masks: slots 0, 2 hold even symbols, slots 1, 3 odd ones
 			const int c0n = __popcll(member[0]), c2n = __popcll(member[2]), c1n = __popcll(member[1]);
@@ -705,7 +721,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		run(0, nA[jc], std::false_type{}, std::false_type{});
 		run(nA[jc], n0[jc], std::false_type{}, std::true_type{});
 		run(n0[jc], nC[jc], std::true_type{}, std::false_type{});
-		run(nC[jc], NM, std::true_type{}, std::true_type{});
+		run(nC[jc], nmr, std::true_type{}, std::true_type{});
 	};
 	// c2v[a] = shape(S[h_x a] - S[0]) (:899-916): the output goes back to the variable domain through LDS
 	auto emit_stage = [&](int x, double *Sx) {
@@ -805,10 +821,10 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 
 bool nbl_ems256_applicable(const NblGraphDev &g, bool all_dc4, int nm, int nc)
 {
-	return g.q == 256 && all_dc4 && nc >= 1 && (nm == 8 || nm == 16 || nm == 32 || nm == 64) && g.ems_toff != nullptr; // (fused: g.dv2_row too, see fused_shape)
+	return g.q == 256 && all_dc4 && nc >= 1 && nm >= 1 && nm <= 64 && g.ems_toff != nullptr; // (fused: g.dv2_row too, see fused_shape)
 }
 
-size_t nbl_ems256_lds_bytes(int nm) { return 3 * Q * 8 + (size_t)4 * nm * 16; }
+size_t nbl_ems256_lds_bytes(int nm) { return 3 * Q * 8 + (size_t)4 * (nm <= 8 ? 8 : nm <= 16 ? 16 : nm <= 32 ? 32 : 64) * 16; }
 
 template <int NM, bool FUSED>
 static void launch_nc(int nc, dim3 grid, dim3 block, hipStream_t st, const NblGraphDev &g, const NblWork &w, const NblRun &r)
@@ -827,7 +843,12 @@ hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const Nb
 		case 16: launch_nc<16, true>(r.nc, grid, block, st, g, w, r); break;
 		case 32: launch_nc<32, true>(r.nc, grid, block, st, g, w, r); break;
 		case 64: launch_nc<64, true>(r.nc, grid, block, st, g, w, r); break;
-		default: return hipErrorInvalidValue;
+		default: // any other nm <= 64 (nbl_ems256_applicable): the layout of the next power of two
+			if (r.nm < 8) launch_nc<-8, true>(r.nc, grid, block, st, g, w, r);
+			else if (r.nm < 16) launch_nc<-16, true>(r.nc, grid, block, st, g, w, r);
+			else if (r.nm < 32) launch_nc<-32, true>(r.nc, grid, block, st, g, w, r);
+			else launch_nc<-64, true>(r.nc, grid, block, st, g, w, r);
+			break;
 		}
 	} else {
 		switch (r.nm) {
@@ -835,7 +856,12 @@ hipError_t nbl_launch_cn_ems256(const NblGraphDev &g, const NblWork &w, const Nb
 		case 16: launch_nc<16, false>(r.nc, grid, block, st, g, w, r); break;
 		case 32: launch_nc<32, false>(r.nc, grid, block, st, g, w, r); break;
 		case 64: launch_nc<64, false>(r.nc, grid, block, st, g, w, r); break;
-		default: return hipErrorInvalidValue;
+		default:
+			if (r.nm < 8) launch_nc<-8, false>(r.nc, grid, block, st, g, w, r);
+			else if (r.nm < 16) launch_nc<-16, false>(r.nc, grid, block, st, g, w, r);
+			else if (r.nm < 32) launch_nc<-32, false>(r.nc, grid, block, st, g, w, r);
+			else launch_nc<-64, false>(r.nc, grid, block, st, g, w, r);
+			break;
 		}
 	}
 	return hipGetLastError();

@@ -173,10 +173,10 @@ def test_all_ties_and_erasures(oracle, codename, nm, nc):
 
 
 @pytest.mark.parametrize("nc", [1, 2, 3, 4])
-@pytest.mark.parametrize("nm", [8, 16, 32, 64])
+@pytest.mark.parametrize("nm", [8, 16, 32, 64, 1, 5, 24, 33, 48, 63])
 def test_every_shape_of_the_specialised_kernel_vs_oracle(oracle, nm, nc):
-    """Real-valued inputs, every (nm, nc) the GF(256) dc=4 fast path accepts (nm = 8, 16, 32, 64; nc = 4 equals nc = 3 at check
-    degree 4): message state after 3 iterations bit-identical to the canonical oracle in all three kernel variants, shaped
+    """Real-valued inputs, (nm, nc) over everything the GF(256) dc=4 fast path accepts (nm = 8, 16, 32, 64 as compile-time
+    constants, any other nm <= 64 at run time on the 64-entry layout; nc = 4 equals nc = 3 at check degree 4): message state after 3 iterations bit-identical to the canonical oracle in all three kernel variants, shaped
     outputs (factor / offset dead-zone) included."""
     codename = "divsalar.UNBLDPC.128.64.GF.256"
     code = nb.Code(codename)
@@ -204,7 +204,7 @@ def test_every_shape_of_the_specialised_kernel_vs_oracle(oracle, nm, nc):
 
 
 @pytest.mark.parametrize("nc", [1, 2, 3])
-@pytest.mark.parametrize("nm", [8, 16, 32, 64])
+@pytest.mark.parametrize("nm", [8, 16, 32, 64, 3, 24, 47])
 @pytest.mark.parametrize("seed", [1, 2])
 def test_random_ties_all_kernel_variants(oracle, nm, seed, nc):
     """Coarsely quantised random LLRs: hundreds of exact ties per vector, in the cut bucket of the top-nm selection, at rank 0

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the other BASELINE.json configurations (parity-test cases, not the headline bench line).
 
-usage: python tools/bench_config.py cfg1|cfg2|cfg3|cfg3nc2|cfg4|cfg5|tems256|ems64|bp64|ems16|tems16|bp16 [batch] [steps] [ebn0]
+usage: python tools/bench_config.py cfg1|cfg2|cfg3|cfg3nc2|cfg3nm24|cfg3nm48|cfg3nm64|cfg4|cfg5|tems256|ems64|bp64|ems16|tems16|bp16 [batch] [steps] [ebn0]
 Prints one JSON line: codewords/s at fixed iterations with HBM-resident inputs, plus the algorithmic-bytes roofline fraction
 (8(q-1)[N + I(N + 4E + D E)] + 4N + 4 bytes per codeword, D = 1 for BP / T-EMS).
 """
@@ -21,6 +21,9 @@ CFG = {
     "cfg2": dict(code="divsalar.UNBLDPC.128.64.GF.256", method=nb.METHOD_EMS, iters=50, batch=4096, kw=dict(ems_nm=16, ems_nc=3), D=0, ebn0=2.0, mod="bpsk"),
     "cfg3": dict(code="divsalar.UNBLDPC.512.256.GF.256", method=nb.METHOD_EMS, iters=50, batch=16384, kw=dict(ems_nm=32, ems_nc=3), D=0, ebn0=1.0, mod="bpsk"),
     "cfg3nc2": dict(code="divsalar.UNBLDPC.512.256.GF.256", method=nb.METHOD_EMS, iters=50, batch=4096, kw=dict(ems_nm=32, ems_nc=2), D=0, ebn0=1.0, mod="bpsk"),
+    "cfg3nm24": dict(code="divsalar.UNBLDPC.512.256.GF.256", method=nb.METHOD_EMS, iters=50, batch=4096, kw=dict(ems_nm=24, ems_nc=3), D=0, ebn0=1.0, mod="bpsk"),
+    "cfg3nm48": dict(code="divsalar.UNBLDPC.512.256.GF.256", method=nb.METHOD_EMS, iters=50, batch=4096, kw=dict(ems_nm=48, ems_nc=3), D=0, ebn0=1.0, mod="bpsk"),
+    "cfg3nm64": dict(code="divsalar.UNBLDPC.512.256.GF.256", method=nb.METHOD_EMS, iters=50, batch=4096, kw=dict(ems_nm=64, ems_nc=3), D=0, ebn0=1.0, mod="bpsk"),
     "cfg4": dict(code="BDS.576.288.GF.64", method=nb.METHOD_TEMS, iters=50, batch=8192, kw=dict(tems_nr=2, tems_nc=3), D=1, ebn0=3.0, mod="qam"),
     # shapes without a specialised kernel (general kernels)
     "tems256": dict(code="divsalar.UNBLDPC.512.256.GF.256", method=nb.METHOD_TEMS, iters=50, batch=2048, kw=dict(tems_nr=2, tems_nc=3), D=1, ebn0=1.5, mod="bpsk"),
