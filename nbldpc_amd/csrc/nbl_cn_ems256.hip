@@ -598,6 +598,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	// ---- conf(nm,nc): truncated max-plus convolutions --------------------------------------------------------------
 	// dst[t_a ^ t_b ^ sxor] = max over the nm x nm entry pairs of (v_a + bias) + v_b   (bias = 0: plain pair convolution)
 	constexpr int PER = 64 >> LOGNM, ROUNDS = (NM << LOGNM) >> 6;
+	const int rounds = VARNM ? (nmr + PER - 1) >> (6 - LOGNM) : ROUNDS; // (run-time nm: the moving operand stops at the nm-th entry)
 	// list position of the lane's fixed operand: neighbouring lanes alternate between the front (even symbols) and the back (odd
 	// symbols) of the list -- a run of 16 even symbols would only reach half of the LDS banks of the scatter
 	const int apos = (lane & 1) ? (NM - 1) - ((lane & (NM - 1)) >> 1) : ((lane & (NM - 1)) >> 1);
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		ea.t8 ^= sxor << 3;
 		WSYNC();
 #pragma unroll
-		for (int it = 0; it < ROUNDS; it++) {
+		for (int it = 0; it < rounds; it++) {
 			const ListEnt eb = list_at(jb, it * PER + (lane >> LOGNM));
 			__hip_atomic_fetch_max((double *)((char *)dst + (ea.t8 ^ eb.t8)), ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		ea.v = ea.v + bias;
 		ea.t8 ^= sxor << 3;
 #pragma unroll
-		for (int it = 0; it < ROUNDS; it++) {
+		for (int it = 0; it < rounds; it++) {
 			const ListEnt eb = list_at(jb, it * PER + (lane >> LOGNM));
 			__hip_atomic_fetch_max((double *)((char *)dst + (ea.t8 ^ eb.t8)), ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			const ListEnt ea0 = list_at(0, apos), ea1 = list_at(1, apos);
 			WSYNC();
 #pragma unroll
-			for (int it = 0; it < ROUNDS; it++) {
+			for (int it = 0; it < rounds; it++) {
 				const ListEnt eb1 = list_at(1, it * PER + (lane >> LOGNM)), eb2 = list_at(2, it * PER + (lane >> LOGNM));
 #if NBL_WHATIF == 3 // diagnostic (wrong results): the pair convolutions without their LDS atomics
 				double keep = (ea0.v + eb1.v) + ((ea0.v + eb2.v) + (ea1.v + eb2.v));
