@@ -9,9 +9,10 @@
 //   * layer 0 (no deviation) is the constant {0 at check sum 0}, so layer 1 (one deviating column) is a per-lane minimum
 //     over the marked columns -- no convolution; only layers 2 and 3 gather a predecessor state `S[s ^ q]` from LDS, and
 //     they read just the 24 bytes they need (cost and path code of layers 1, 2) instead of a 48-byte record;
-//   * candidate lists are compacted with ballots (no LDS atomics), the four outputs are formed together (3 barriers instead
-//     of 12), wave reductions run on the DPP network.
+//   * the candidates of a column are read from the registers of their lanes (ballot + v_readlane: no list in LDS), the four
+//     outputs are formed together (3 barriers instead of 12), wave reductions run on the DPP network.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "nbl_device.h"
 #include "nbl_kernels.h"
 
@@ -19,7 +20,6 @@ namespace {
 
 constexpr int Q = 64, P = 6, DC = 4;
 
-struct __attribute__((aligned(16))) Cand { double u; int q16; unsigned dig; }; // q16 = 16 q: byte-offset XOR of the state gather; dig = q << digit shift
 
 // smaller cost wins, equal cost: smaller path code (= earlier in the reference's enumeration order): the lexicographic
 // comparison as mask arithmetic (three compares, the AND / OR on the scalar unit), then one select for the code; the cost
@@ -28,6 +28,16 @@ __device__ __forceinline__ void relax(double &bv, unsigned &bc, double val, unsi
 {
 	const bool take = (val < bv) | ((val == bv) & (code < bc));
 	bc = take ? code : bc;
+	bv = __builtin_fmin(bv, val);
+}
+
+// the same without the comparison of the path codes: right unless val == bv in some lane, which `tie` records (a wave-wide mask
+// kept on the scalar unit) -- the caller then repeats the column with relax().  Costs that stand for "no path" must be NaN
+// here, not infinity: inf == inf would report a tie at every unreachable check sum, NaN compares false and fmin drops it.
+__device__ __forceinline__ void relax_untied(double &bv, unsigned &bc, double val, unsigned code, uint64_t &tie)
+{
+	tie |= __ballot(val == bv);
+	bc = (val < bv) ? code : bc;
 	bv = __builtin_fmin(bv, val);
 }
 
@@ -42,12 +52,13 @@ template <bool FUSED, int NC>
 __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	__shared__ double dU[DC][Q];                            // delta-domain trellis (:1814-1834)
-	// one phased region: during the dynamic programme the predecessor states and the candidate list, afterwards the extrinsic
-	// minima of the four outputs (4.7 KB of LDS per wave in all: the register count, not LDS, sets the waves per SIMD)
-	__shared__ __attribute__((aligned(16))) char phased[Q * 16 + Q * 8 + (Q + 4) * 16];
-	double2 *const Sv = (double2 *)phased;                  // [Q] cost of layers 1, 2 of every check sum before the current column
-	uint2 *const Sc = (uint2 *)(phased + Q * 16);           // [Q] their path codes
-	Cand *const cl = (Cand *)(phased + Q * 16 + Q * 8);     // [Q + 4] candidates of the column being folded
+	// one phased region: during the dynamic programme the predecessor states, afterwards the extrinsic minima of the four
+	// outputs (4 KB of LDS per wave in all: the register count, not LDS, sets the waves per SIMD)
+	__shared__ __attribute__((aligned(16))) char phased[DC * Q * 8];
+	// cost of layers 1, 2 of every check sum before the current column and their path codes: three arrays of 8-byte entries, so
+	// that one XOR gives the address of all three gathers (NaN = no path: relax_untied)
+	double *const Sv1 = (double *)phased, *const Sv2 = Sv1 + Q; // [Q], [Q]
+	uint2 *const Sc = (uint2 *)(phased + Q * 16);           // [Q]
 	double (*const Lc)[Q] = (double (*)[Q])phased;          // [DC][Q] extrinsic minima of every output edge (:1075-1102), after the DP
 	static_assert(sizeof(phased) >= DC * Q * 8, "Lc must fit the phased region");
 	const int lane = lane_id();
@@ -160,56 +171,66 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 		o0 = (rank == 0) ? d : o0;
 		o1 = (rank == 1) ? d : o1;
 	}
-	// deviation candidates of column d: non-zero symbols only (symbol 0 = "no deviation"), ascending symbol order, padded to a
-	// multiple of four with entries that can never win; returns the padded count
-	auto build_candidates = [&](int d) {
-		const bool c = ((mask >> d) & 1) && lane > 0;
-		const uint64_t bal = __ballot(c);
-		const int n = uniform(__builtin_popcountll(bal));
-		if (c) {
-			Cand e;
-			e.u = pick(u, d);
-			e.q16 = lane << 4;
-			e.dig = (unsigned)lane << (P * (DC - 1 - d));
-			cl[prefix_count(bal)] = e;
-		}
-		const int n4 = (n + 3) & ~3;
-		if (lane < 4 && n + lane < n4) {
-			Cand e;
-			e.u = __builtin_huge_val();
-			e.q16 = 0;
-			e.dig = 0;
-			cl[n + lane] = e;
-		}
-		return n4;
-	};
-
 	// ---- 3. min-plus dynamic programme over the columns; v[l], c[l] = best path with exactly l deviating columns -----------
 	const double INF = __builtin_huge_val();
-	const int lane16 = lane << 4;
+	int lane8 = lane << 3;
+	asm("" : "+v"(lane8)); // (opaque: otherwise (lane << 3) ^ (q << 3) becomes (lane ^ q) << 3, a second vector instruction per gather)
 	double v1 = INF, v2 = INF, v3 = INF;
 	unsigned c1 = 0, c2 = 0, c3 = 0;
 	if (((mask >> 0) & 1) && lane > 0) { v1 = u[0]; c1 = (unsigned)lane << (P * (DC - 1)); }
+	// one column folded into layers 2 (and 3): every candidate (cost ud at deviation symbol q, digit q << sh) against the
+	// predecessor state of check sum s ^ q.  Candidates = the marked non-zero symbols of the column (symbol 0 = "no deviation"),
+	// in ascending order: they are taken straight from the registers of their lanes (v_readlane into scalar operands of the
+	// adds) -- a candidate list in LDS would cost a 16-byte broadcast read per candidate on top of the 24 bytes of the gather,
+	// and the LDS port is as busy as the vector unit in this kernel
+	auto fold = [&](auto exact_tag, bool both, uint64_t cm, double ud, int sh, uint64_t &tie) {
+		constexpr bool EXACT = decltype(exact_tag)::value;
+		auto one = [&](int q) {
+			const double cu = read_lane_f64(ud, q);
+			const unsigned dig = (unsigned)q << sh;
+			const int off = lane8 ^ (q << 3);
+			const double s1 = *(const double *)((const char *)Sv1 + off);
+			const uint2 sc = *(const uint2 *)((const char *)Sc + off);
+			if (EXACT) relax(v2, c2, s1 + cu, sc.x + dig);
+			else relax_untied(v2, c2, s1 + cu, sc.x + dig, tie);
+			if (both) {
+				const double s2 = *(const double *)((const char *)Sv2 + off);
+				if (EXACT) relax(v3, c3, s2 + cu, sc.y + dig);
+				else relax_untied(v3, c3, s2 + cu, sc.y + dig, tie);
+			}
+		};
+		int left = __builtin_popcountll(cm);
+		for (; left >= 4; left -= 4) {
+			int q[4];
+#pragma unroll
+			for (int t = 0; t < 4; t++) { q[t] = __builtin_ctzll(cm); cm &= cm - 1; }
+#pragma unroll
+			for (int t = 0; t < 4; t++) one(q[t]);
+		}
+		for (; left > 0; left--) { const int q = __builtin_ctzll(cm); cm &= cm - 1; one(q); }
+	};
 #pragma unroll
 	for (int d = 1; d < DC; d++) {
 		const int sh = P * (DC - 1 - d); // digit of column d in the path code
-		Sv[lane] = make_double2(v1, v2);
+		const double NOPATH = __builtin_nan("");
+		Sv1[lane] = (v1 == INF) ? NOPATH : v1;
+		Sv2[lane] = (v2 == INF) ? NOPATH : v2;
 		Sc[lane] = make_uint2(c1, c2);
-		const int n4d = (nc >= 2) ? build_candidates(d) : 0;
 		__syncthreads();
 		if (nc >= 2) {
-			for (int k = 0; k < n4d; k += 4) {
-				Cand e[4];
-#pragma unroll
-				for (int t = 0; t < 4; t++) e[t] = cl[k + t]; // LDS broadcast
-#pragma unroll
-				for (int t = 0; t < 4; t++) {
-					const int off = lane16 ^ e[t].q16;
-					const double2 sv = *(const double2 *)((const char *)Sv + off);
-					const uint2 sc = *(const uint2 *)((const char *)Sc + (off >> 1));
-					relax(v2, c2, sv.x + e[t].u, sc.x + e[t].dig);
-					if (d >= 2 && nc >= 3) relax(v3, c3, sv.y + e[t].u, sc.y + e[t].dig);
-				}
+			const uint64_t cm = __ballot(((mask >> d) & 1) && lane > 0);
+			const double v2s = v2, v3s = v3;
+			const unsigned c2s = c2, c3s = c3;
+			uint64_t tie = 0;
+			if (d >= 2 && nc >= 3) fold(std::false_type{}, true, cm, u[d], sh, tie);
+			else fold(std::false_type{}, false, cm, u[d], sh, tie);
+#ifdef NBL_T64_NOTIE
+			tie = 0; // diagnostic (wrong results on ties): never repeat a column
+#endif
+			if (tie) { // equal costs somewhere: the column again, path codes compared (integer-valued LLRs, dead-zone zeros)
+				v2 = v2s; v3 = v3s; c2 = c2s; c3 = c3s;
+				if (d >= 2 && nc >= 3) fold(std::true_type{}, true, cm, u[d], sh, tie);
+				else fold(std::true_type{}, false, cm, u[d], sh, tie);
 			}
 		}
 		if (((mask >> d) & 1) && lane > 0) relax(v1, c1, u[d], (unsigned)lane << sh);
