@@ -34,11 +34,14 @@ __device__ __forceinline__ void relax(double &bv, unsigned &bc, double val, unsi
 // the same without the comparison of the path codes: right unless val == bv in some lane, which `tie` records (a wave-wide mask
 // kept on the scalar unit) -- the caller then repeats the column with relax().  Costs that stand for "no path" must be NaN
 // here, not infinity: inf == inf would report a tie at every unreachable check sum, NaN compares false and fmin drops it.
-__device__ __forceinline__ void relax_untied(double &bv, unsigned &bc, double val, unsigned code, uint64_t &tie)
+// What it keeps instead of the path code is `from`, the LDS offset of the winning predecessor: the code is formed once per column
+// from it (predecessor's code + this column's digit), not once per candidate.
+__device__ __forceinline__ void relax_untied(double &bv, int &from, double val, int off, uint64_t &tie)
 {
 	tie |= __ballot(val == bv);
-	bc = (val < bv) ? code : bc;
-	bv = __builtin_fmin(bv, val);
+	from = (val < bv) ? off : from;
+	// (v_min_f64 as such: behind __builtin_fmin the compiler first canonicalises the running minimum, an instruction per chain and trip)
+	asm("v_min_f64 %0, %1, %2" : "=v"(bv) : "v"(bv), "v"(val));
 }
 
 __device__ __forceinline__ double pick(const double (&u)[DC], int k)
@@ -185,18 +188,20 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 	// and the LDS port is as busy as the vector unit in this kernel
 	auto fold = [&](auto exact_tag, bool both, uint64_t cm, double ud, int sh, uint64_t &tie) {
 		constexpr bool EXACT = decltype(exact_tag)::value;
+		int from2 = lane8, from3 = lane8;
+		const double v2in = v2, v3in = v3;
 		auto one = [&](int q) {
 			const double cu = read_lane_f64(ud, q);
-			const unsigned dig = (unsigned)q << sh;
 			const int off = lane8 ^ (q << 3);
 			const double s1 = *(const double *)((const char *)Sv1 + off);
-			const uint2 sc = *(const uint2 *)((const char *)Sc + off);
-			if (EXACT) relax(v2, c2, s1 + cu, sc.x + dig);
-			else relax_untied(v2, c2, s1 + cu, sc.x + dig, tie);
-			if (both) {
-				const double s2 = *(const double *)((const char *)Sv2 + off);
-				if (EXACT) relax(v3, c3, s2 + cu, sc.y + dig);
-				else relax_untied(v3, c3, s2 + cu, sc.y + dig, tie);
+			if (EXACT) {
+				const unsigned dig = (unsigned)q << sh;
+				const uint2 sc = *(const uint2 *)((const char *)Sc + off);
+				relax(v2, c2, s1 + cu, sc.x + dig);
+				if (both) relax(v3, c3, *(const double *)((const char *)Sv2 + off) + cu, sc.y + dig);
+			} else {
+				relax_untied(v2, from2, s1 + cu, off, tie);
+				if (both) relax_untied(v3, from3, *(const double *)((const char *)Sv2 + off) + cu, off, tie);
 			}
 		};
 		int left = __builtin_popcountll(cm);
@@ -208,6 +213,14 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 			for (int t = 0; t < 4; t++) one(q[t]);
 		}
 		for (; left > 0; left--) { const int q = __builtin_ctzll(cm); cm &= cm - 1; one(q); }
+		if (!EXACT) { // the path codes of the layers this column improved (strictly: an equal cost is a tie and ends in the exact pass)
+			const unsigned n2 = Sc[from2 >> 3].x + ((unsigned)((from2 ^ lane8) >> 3) << sh);
+			c2 = (v2 < v2in) ? n2 : c2;
+			if (both) {
+				const unsigned n3 = Sc[from3 >> 3].y + ((unsigned)((from3 ^ lane8) >> 3) << sh);
+				c3 = (v3 < v3in) ? n3 : c3;
+			}
+		}
 	};
 #pragma unroll
 	for (int d = 1; d < DC; d++) {
