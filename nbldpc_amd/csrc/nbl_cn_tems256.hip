@@ -6,14 +6,17 @@
 //
 //   * lane l owns the delta-domain symbols l, 64+l, 128+l, 192+l: trellis columns, column order, candidate marks and every
 //     dynamic-programme state of those four check sums live in registers;
-//   * layer 1 is a per-lane minimum (layer 0 is the constant {0 at check sum 0}); layers 2 and 3 gather the 24-byte predecessor
-//     record S[s ^ q] from LDS: for the lane's four symbols that is one address (lane ^ q) XOR-ed with the four plane offsets;
+//   * layer 1 is a per-lane minimum (layer 0 is the constant {0 at check sum 0}); layers 2 and 3 gather the predecessor state
+//     S[s ^ q] from LDS: for the lane's four symbols that is one address (lane ^ q) XOR-ed with the four plane offsets; the
+//     candidates (q, cost) themselves come from the registers of their lanes (ballot + v_readlane), and the path codes are only
+//     compared when a cost ties (relax_untied);
 //   * LDS per wave: one 10 KB region used in phases (trellis while it is built and again in the output stage, predecessor
-//     records + ONE column's candidate list during the programme, one output vector at a time) against 51 KB of the general
-//     kernel, which runs less than one wave per SIMD at q = 256.
+//     state during the programme, one output vector at a time) against 51 KB of the general kernel, which runs less than one
+//     wave per SIMD at q = 256.
 // FUSED = true additionally runs the variable-node pass of the iteration for the four incoming edges (dv = 2 codes), exactly
 // as nbl_cn_tems64.hip does.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "nbl_device.h"
 #include "nbl_kernels.h"
 
@@ -21,7 +24,6 @@ namespace {
 
 constexpr int Q = 256, P = 8, DC = 4, NS = 4;
 
-struct __attribute__((aligned(16))) Cand { double u; int q16; unsigned dig; }; // cost, symbol << 4, symbol << digit shift
 
 // smaller cost wins, equal cost: smaller path code (= earlier in the reference's enumeration order): the lexicographic
 // comparison as mask arithmetic (three compares, the AND / OR on the scalar unit), then one select for the code; the cost
@@ -31,6 +33,16 @@ __device__ __forceinline__ void relax(double &bv, unsigned &bc, double val, unsi
 	const bool take = (val < bv) | ((val == bv) & (code < bc));
 	bc = take ? code : bc;
 	bv = __builtin_fmin(bv, val);
+}
+
+// the same without the comparison of the path codes (nbl_cn_tems64.hip): right unless val == bv in some lane, which `tie` records
+// (a wave-wide mask on the scalar unit) -- the caller then repeats the column with relax().  `from` = LDS offset of the winning
+// predecessor: the path code is formed from it once per column.  "No path" must be NaN here, not infinity (inf == inf is a tie).
+__device__ __forceinline__ void relax_untied(double &bv, int &from, double val, int off, uint64_t &tie)
+{
+	tie |= __ballot(val == bv);
+	from = (val < bv) ? off : from;
+	asm("v_min_f64 %0, %1, %2" : "=v"(bv) : "v"(bv), "v"(val)); // (__builtin_fmin canonicalises the running minimum first)
 }
 
 __device__ __forceinline__ double pick(const double (&u)[DC], int k)
@@ -44,16 +56,15 @@ template <bool FUSED, int NC>
 __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	// One 10 KB region, used in two phases (sixteen waves per CU = four per SIMD; the register count allows as many):
-	//   programme:  predecessor records Sv (4 KB: 16-byte cost pairs) | Sc (2 KB: 8-byte code pairs) + the candidate list of the
-	//               current column (4 KB: at most 255 candidates, padded to a multiple of four)
+	//   programme:  predecessor state Sv1 | Sv2 (2 KB each: costs of layers 1, 2) | Sc (2 KB: 8-byte code pairs) -- three arrays of
+	//               8-byte entries, so one offset serves all three gathers and each touches every LDS bank once -- and the
+	//               column-start copy of layer 3 (3 KB), which only the exact pass after a tie reads
 	//   before / after it:  the trellis dU (8 KB, rebuilt from registers for the output stage) + one output vector Lc (2 KB)
-	// Every record is read with the stride of its own size (16-byte costs, 8-byte codes), so a gather touches every LDS bank
-	// once: the 8-byte codes used to sit in 16-byte slots, and their reads at a 16-byte stride reached only half of the banks.
 	__shared__ __attribute__((aligned(16))) char lds[Q * 16 + Q * 8 + Q * 16];
-	char *Sraw = lds;                                      // predecessor records
-	double2 *Sv = (double2 *)Sraw;                         // [Q] cost of layers 1, 2 of every check sum before the current column
-	uint2 *Sc = (uint2 *)(Sraw + Q * 16);                  // [Q] their path codes (x, y)
-	Cand *cl = (Cand *)(lds + Q * 16 + Q * 8);             // [Q] deviation candidates of the current column
+	double *Sv1 = (double *)lds, *Sv2 = Sv1 + Q;           // [Q], [Q] cost of layers 1, 2 of every check sum before the current column (NaN = no path)
+	uint2 *Sc = (uint2 *)(lds + Q * 16);                   // [Q] their path codes (x, y)
+	double *V3s = (double *)(lds + Q * 24);                // [Q] layer 3 at the start of the column, cost
+	unsigned *C3s = (unsigned *)(lds + Q * 32);            // [Q] and path code (read back only when the column ties)
 	double (*dU)[Q] = (double (*)[Q])lds;                  // [DC][Q] delta-domain trellis (:1814-1834)
 	double *Lc = (double *)(lds + DC * Q * 8);             // [Q] extrinsic minima of one output edge at a time (:1075-1102)
 
@@ -168,54 +179,97 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 		const int s = lane + 64 * i;
 		if ((mask[i] & 1) && s > 0) { st[i].v1 = u[i][0]; st[i].c1 = (unsigned)s << (P * (DC - 1)); }
 	}
-	const int lane16 = lane << 4;
+	int lane8 = lane << 3;
+	asm("" : "+v"(lane8)); // (opaque: otherwise (lane << 3) ^ (q << 3) becomes (lane ^ q) << 3, a second vector instruction per gather)
+	// one candidate (cost cu at deviation symbol q) of column d folded into layers 2 (and 3) of the lane's four check sums:
+	// the predecessor of check sum s is s ^ q -- one offset (lane ^ q) XOR-ed with the four plane offsets
+	auto fold_one = [&](auto exact_tag, bool both, int q, double cu, int sh, int (&from2)[NS], int (&from3)[NS], uint64_t &tie) __attribute__((always_inline)) {
+		constexpr bool EXACT = decltype(exact_tag)::value;
+		const int A = lane8 ^ (q << 3);
 #pragma unroll
-	for (int d = 1; d < DC; d++) {
-		const int sh = P * (DC - 1 - d); // digit of column d in the path code
-		// predecessor records and the candidates of this column (non-zero symbols, symbol 0 = "no deviation")
-		int base = 0;
+		for (int i = 0; i < NS; i++) {
+			const int off = A ^ (i << 9);
+			const double s1 = *(const double *)((const char *)Sv1 + off);
+			if (EXACT) {
+				const unsigned dig = (unsigned)q << sh;
+				const uint2 sc = *(const uint2 *)((const char *)Sc + off);
+				relax(st[i].v2, st[i].c2, s1 + cu, sc.x + dig);
+				if (both) relax(st[i].v3, st[i].c3, *(const double *)((const char *)Sv2 + off) + cu, sc.y + dig);
+			} else {
+				relax_untied(st[i].v2, from2[i], s1 + cu, off, tie);
+				if (both) relax_untied(st[i].v3, from3[i], *(const double *)((const char *)Sv2 + off) + cu, off, tie);
+			}
+		}
+	};
+	// the whole column: its candidates are the marked non-zero symbols (symbol 0 = "no deviation"), read from the registers of
+	// their lanes plane by plane (ballot + v_readlane: no candidate list in LDS)
+	auto fold = [&](auto exact_tag, auto both_tag, auto d_tag, uint64_t cm0, uint64_t cm1, uint64_t cm2, uint64_t cm3, uint64_t &tie) __attribute__((always_inline)) {
+		constexpr bool EXACT = decltype(exact_tag)::value, both = decltype(both_tag)::value;
+		constexpr int D = decltype(d_tag)::value, sh = P * (DC - 1 - D);
+		int from2[NS], from3[NS]; // (start: the check sum's own offset, which no candidate produces -- q = 0 is none)
+#pragma unroll
+		for (int i = 0; i < NS; i++) from2[i] = from3[i] = lane8 ^ (i << 9);
+#pragma unroll
+		for (int ip = 0; ip < NS; ip++) {
+			uint64_t m = ip == 0 ? cm0 : ip == 1 ? cm1 : ip == 2 ? cm2 : cm3;
+			int left = __builtin_popcountll(m);
+			for (; left >= 2; left -= 2) {
+				const int l0 = __builtin_ctzll(m);
+				m &= m - 1;
+				const int l1 = __builtin_ctzll(m);
+				m &= m - 1;
+				const double cu0 = read_lane_f64(u[ip][D], l0), cu1 = read_lane_f64(u[ip][D], l1);
+				fold_one(exact_tag, both, l0 + 64 * ip, cu0, sh, from2, from3, tie);
+				fold_one(exact_tag, both, l1 + 64 * ip, cu1, sh, from2, from3, tie);
+			}
+			if (left) {
+				const int l0 = __builtin_ctzll(m);
+				fold_one(exact_tag, both, l0 + 64 * ip, read_lane_f64(u[ip][D], l0), sh, from2, from3, tie);
+			}
+		}
+		if (!EXACT) { // the path codes of the layers this column improved
+#pragma unroll
+			for (int i = 0; i < NS; i++) {
+				const int own = lane8 ^ (i << 9);
+				const unsigned n2 = Sc[from2[i] >> 3].x + ((unsigned)((from2[i] ^ own) >> 3) << sh);
+				st[i].c2 = (from2[i] != own) ? n2 : st[i].c2;
+				if (both) {
+					const unsigned n3 = Sc[from3[i] >> 3].y + ((unsigned)((from3[i] ^ own) >> 3) << sh);
+					st[i].c3 = (from3[i] != own) ? n3 : st[i].c3;
+				}
+			}
+		}
+	};
+	auto column = [&](auto d_tag) __attribute__((always_inline)) {
+		constexpr int d = decltype(d_tag)::value, sh = P * (DC - 1 - d); // sh = digit of column d in the path code
+		const double NOPATH = __builtin_nan("");
+		uint64_t cm[NS];
 #pragma unroll
 		for (int i = 0; i < NS; i++) {
 			const int s = lane + 64 * i;
-			Sv[s] = make_double2(st[i].v1, st[i].v2);
+			Sv1[s] = (st[i].v1 == INF) ? NOPATH : st[i].v1;
+			Sv2[s] = (st[i].v2 == INF) ? NOPATH : st[i].v2;
 			Sc[s] = make_uint2(st[i].c1, st[i].c2);
-			const bool c = ((mask[i] >> d) & 1) && s > 0;
-			const uint64_t bal = __ballot(c);
-			if (c) {
-				Cand e;
-				e.u = u[i][d];
-				e.q16 = s << 4;
-				e.dig = (unsigned)s << sh;
-				cl[base + prefix_count(bal)] = e;
-			}
-			base += uniform(__builtin_popcountll(bal));
-		}
-		const int n = base, n4 = (n + 3) & ~3;
-		if (lane < 4 && n + lane < n4) { // pad to a multiple of four with entries that can never win
-			Cand e;
-			e.u = INF;
-			e.q16 = 0;
-			e.dig = 0;
-			cl[n + lane] = e;
+			V3s[s] = st[i].v3; // (what the exact pass starts from, should this column tie)
+			C3s[s] = st[i].c3;
+			cm[i] = __ballot(((mask[i] >> d) & 1) && s > 0);
 		}
 		__syncthreads();
 		if (nc >= 2) {
-			for (int k = 0; k < n4; k += 2) {
-				Cand e[2];
+			uint64_t tie = 0;
+			constexpr bool both = (d >= 2 && nc >= 3);
+			fold(std::false_type{}, std::integral_constant<bool, both>{}, std::integral_constant<int, d>{}, cm[0], cm[1], cm[2], cm[3], tie);
+			if (tie) { // equal costs somewhere: the column again from its start, path codes compared
 #pragma unroll
-				for (int t = 0; t < 2; t++) e[t] = cl[k + t]; // LDS broadcast
-#pragma unroll
-				for (int t = 0; t < 2; t++) {
-					const int A = lane16 ^ e[t].q16; // byte offset of record (lane ^ q) for the lane's symbol 0; symbol i: XOR i << 10
-#pragma unroll
-					for (int i = 0; i < NS; i++) {
-						const int off = A ^ (i << 10);
-						const double2 sv = *(const double2 *)(Sraw + off);
-						const uint2 sc = *(const uint2 *)(Sraw + Q * 16 + (off >> 1));
-						relax(st[i].v2, st[i].c2, sv.x + e[t].u, sc.x + e[t].dig);
-						if (d >= 2 && nc >= 3) relax(st[i].v3, st[i].c3, sv.y + e[t].u, sc.y + e[t].dig);
-					}
+				for (int i = 0; i < NS; i++) {
+					const int s = lane + 64 * i;
+					const double v2s = Sv2[s];
+					st[i].v2 = (v2s != v2s) ? INF : v2s;
+					st[i].c2 = Sc[s].y;
+					st[i].v3 = V3s[s];
+					st[i].c3 = C3s[s];
 				}
+				fold(std::true_type{}, std::integral_constant<bool, both>{}, std::integral_constant<int, d>{}, cm[0], cm[1], cm[2], cm[3], tie);
 			}
 		}
 #pragma unroll
@@ -224,7 +278,10 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 			if (((mask[i] >> d) & 1) && s > 0) relax(st[i].v1, st[i].c1, u[i][d], (unsigned)s << sh);
 		}
 		__syncthreads();
-	}
+	};
+	column(std::integral_constant<int, 1>{});
+	column(std::integral_constant<int, 2>{});
+	column(std::integral_constant<int, 3>{});
 	// dW, Eta: best layer of each of the lane's check sums
 	double dW[NS];
 	unsigned eta[NS];
