@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 		}
 		// most reliable symbol: strict '>' over ascending symbols from a running maximum of 0 (:1798-1807) = the lowest symbol
 		// that holds the maximum of {0, v[1..]}; symbol 0 (value 0) when nothing is positive
-		const double mx = wave_fmax(dmax(dmax(v[0], v[1]), dmax(v[2], v[3])));
+		const double mx = wave_fmax_nonneg(dmax(dmax(v[0], v[1]), dmax(v[2], v[3]))); // (symbol 0 holds 0)
 		int arg = 0;
 #pragma unroll
 		for (int i = NS - 1; i >= 0; i--) {

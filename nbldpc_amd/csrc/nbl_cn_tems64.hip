@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 			}
 			double nv = lane == 0 ? 0.0 : post[0] - (ownA[d] ? ca[d] : cb[d]);
 			// DecideLLRVector of the new vector (:1542-1562): lowest symbol among the maxima of {0, nv[1..]}
-			double mx = wave_fmax(nv);
+			double mx = wave_fmax_nonneg(nv); // (lane 0 holds 0)
 			uint64_t hit = __ballot(nv == mx);
 			int arg = hit ? __builtin_ctzll(hit) : 0;
 			int bef = uniform(before[d]);
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 				const double old = first ? ov[d] : V[(size_t)eidx[d] * Q + lane];
 				nv = __dadd_rn(__dmul_rn(r.damp_old, old), __dmul_rn(r.damp_new, nv));
 				if (lane == 0) nv = 0.0;
-				mx = wave_fmax(nv);
+				mx = wave_fmax_nonneg(nv);
 				hit = __ballot(nv == mx);
 				arg = hit ? __builtin_ctzll(hit) : 0;
 			}
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 		int arg;
 		if (FUSED) { mx = vmax[d]; arg = varg[d]; } // found by the variable-node stage above
 		else {
-			mx = wave_fmax(v);
+			mx = wave_fmax_nonneg(v); // (lane 0 holds 0)
 			const uint64_t top = __ballot(v == mx);
 			arg = top ? __builtin_ctzll(top) : 0;
 		}

@@ -122,6 +122,29 @@ __device__ __forceinline__ int wave_imax_id(int x)
 	return __builtin_amdgcn_readlane(x, 63);
 }
 
+__device__ __forceinline__ unsigned wave_umax_id(unsigned x)
+{
+	x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false));
+	x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false));
+	x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false));
+	x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false));
+	x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false));
+	x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false));
+	return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+// Exact wave maximum of max(x, 0) -- what every hard decision and every "most reliable symbol" search needs: the running maximum
+// of DecideLLRVector starts at 0 (NBLDPC.cpp:1545), and symbol 0 carries the value 0.  Non-negative doubles order like their bit
+// patterns, so the maximum is two unsigned 32-bit reductions: the high words, then the low words of the lanes that hold the top
+// high word -- 17 vector instructions, each DPP step folded into its v_max_u32, against 32 for the FP64 reduction (an FP64
+// instruction cannot take a DPP operand: two moves in front of every maximum).  Same value as wave_fmax(max(x, 0)), bit for bit.
+__device__ __forceinline__ double wave_fmax_nonneg(double x)
+{
+	x = dmax(x, 0.0);
+	const unsigned hi = (unsigned)__double2hiint(x), mh = wave_umax_id(hi);
+	const unsigned lo = (hi == mh) ? (unsigned)__double2loint(x) : 0u, ml = wave_umax_id(lo);
+	return __hiloint2double((int)mh, (int)ml);
+}
+
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ double uniform_f64(double v)
@@ -174,7 +197,7 @@ template <int NS> __device__ __forceinline__ int wave_decide(const double (&v)[N
 #pragma unroll
 	for (int i = 0; i < NS; i++)
 		if (lane + 64 * i < q) best = dmax(best, v[i]);
-	const double mx = wave_fmax(best);
+	const double mx = wave_fmax_nonneg(best);
 	int arg = 0;
 #pragma unroll
 	for (int i = NS - 1; i >= 0; i--) { // the lowest symbol that holds the maximum: lowest slot first, then lowest lane
