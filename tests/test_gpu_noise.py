@@ -155,3 +155,22 @@ def test_short_log_and_exp2_on_the_device(tmp_path):
                            os.path.join(root, "tests", "fastmath_device_check.hip"), "-o", exe])
     r = json.loads(subprocess.check_output([exe], text=True))
     assert r["exp2_worst_ulp"] <= 1.0 and r["log_worst_ulp"] <= 1.0, r
+
+
+def test_integer_wave_maximum_on_the_device(tmp_path):
+    """wave_fmax_nonneg (nbl_device.h: the exact maximum of max(x, 0) over a wave as two unsigned 32-bit DPP reductions, used by
+    every hard decision and every most-reliable-symbol search) equals a host evaluation and the FP64 reduction bit for bit on
+    200 000 rows: mixed signs and magnitudes, equal high words, all-negative rows, signed zeros, denormals, infinity, integers."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "wave_reduce_device_check")
+    subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-I", os.path.join(root, "nbldpc_amd", "csrc"),
+                           os.path.join(root, "tests", "wave_reduce_device_check.hip"), "-o", exe])
+    r = json.loads(subprocess.check_output([exe], text=True))
+    assert r["rows"] == 200000 and r["differ_from_host"] == 0 and r["differ_from_fp64_reduction"] == 0, r
+
