@@ -538,11 +538,14 @@ template <int Q> __device__ __forceinline__ SVec get_vec(const BpLds &s, int slo
 	return v;
 }
 
-// out[z] = LSE_x(A[x] + B[z^x]) - LSE_x(A[x] + B[x]) for the lane's symbol z (log domain, out[0] = 0)
-template <int Q> __device__ __forceinline__ double lse_conv_small(const SVec &A, const SVec &B, const BpLds &s, int sl, int gi)
+// The sums of one convolution for the lane's symbol z: sum_x A[x] B[z ^ x] = acc 2^ex exp(A.mx + B.mx)
+struct ConvSum { double acc; int ex; double base_a, base_b; };
+template <int Q> __device__ __forceinline__ ConvSum conv_core_small(const SVec &A, const SVec &B, const BpLds &s, int sl)
 {
 	constexpr int SH = 500; // see lse_conv, nbl_cn_bp256.hip
-	double lse;
+	ConvSum c;
+	c.base_a = A.mx;
+	c.base_b = B.mx;
 	WSYNC();
 	if (fmin(A.rng, B.rng) < 1000.0) { // (uniform inside the group)
 		s.Pa[sl] = ldexp(A.m, A.e + SH);
@@ -551,7 +554,8 @@ template <int Q> __device__ __forceinline__ double lse_conv_small(const SVec &A,
 		double acc = 0.0;
 #pragma unroll 4
 		for (int x = 0; x < Q; x++) acc = __fma_rn(s.Pa[x], s.Pb[sl ^ x], acc);
-		lse = ((nbl_log_pos(acc) - (2 * SH) * LN2) + A.mx) + B.mx;
+		c.acc = acc;
+		c.ex = -2 * SH;
 	} else {
 		s.Pa[sl] = A.m;
 		s.Pb[sl] = B.m;
@@ -568,10 +572,38 @@ template <int Q> __device__ __forceinline__ double lse_conv_small(const SVec &A,
 			const int d = s.Ea[x] + s.Eb[sl ^ x] - ex;
 			acc = __fma_rn(s.Pa[x], ldexp(s.Pb[sl ^ x], d), acc);
 		}
-		lse = ((nbl_log_pos(acc) + (double)ex * LN2) + A.mx) + B.mx;
+		c.acc = acc;
+		c.ex = ex;
 	}
+	return c;
+}
+// ... as a message: out[z] = LSE_x(A[x] + B[z^x]) - LSE_x(A[x] + B[x]) for the lane's symbol z (log domain, out[0] = 0)
+template <int Q> __device__ __forceinline__ double conv_log_small(const ConvSum &c, int sl, int gi)
+{
+	const double lse = ((nbl_log_pos(c.acc) + (double)c.ex * LN2) + c.base_a) + c.base_b;
 	const double norm = __shfl(lse, gi * Q, 64); // z = 0
 	return (sl == 0) ? 0.0 : lse - norm;
+}
+// ... as the operand of the next convolution (conv_xvec, nbl_cn_bp64.hip): the sums already are probabilities, so mantissa and
+// exponent come from the value itself -- no logarithm per symbol, no exponential; reference = the power of two of the group's
+// largest entry, whose log-domain level relative to symbol 0 (= LLR 0, like every vector here) is E_max ln 2 - ln(sum of symbol 0)
+template <int Q> __device__ __forceinline__ SVec conv_svec_small(const ConvSum &c, int gi)
+{
+	SVec r;
+	int fe;
+	r.m = 2.0 * frexp(c.acc, &fe); // acc = (m / 2) 2^fe
+	const int e = fe - 1 + c.ex;
+	const int emax = gmax_i32<Q>(e), nemin = gmax_i32<Q>(-e);
+	r.e = e - emax;
+	const double acc0 = __shfl(c.acc, gi * Q, 64);
+	const int ex0 = __shfl(c.ex, gi * Q, 64);
+	r.mx = (double)(emax - ex0) * LN2 - nbl_log_pos(acc0);
+	r.rng = (double)(emax + nemin + 1) * LN2;
+	return r;
+}
+template <int Q> __device__ __forceinline__ double lse_conv_small(const SVec &A, const SVec &B, const BpLds &s, int sl, int gi)
+{
+	return conv_log_small<Q>(conv_core_small<Q>(A, B, s, sl), sl, gi);
 }
 
 template <int Q, bool FUSED>
@@ -618,10 +650,10 @@ __global__ __launch_bounds__(64) void cn_bp_small_kernel(NblGraphDev g, NblWork 
 	{
 		SVec F = get_vec<Q>(s, 0, sl);
 		for (int k = 1; k <= dc - 2; k++) {
-			const double o = lse_conv_small<Q>(F, get_vec<Q>(s, k, sl), s, sl, gi);
-			if (k + 1 == dc - 1) emit(o, dc - 1);
+			const ConvSum cs = conv_core_small<Q>(F, get_vec<Q>(s, k, sl), s, sl);
+			if (k + 1 == dc - 1) emit(conv_log_small<Q>(cs, sl, gi), dc - 1);
 			else {
-				F = to_svec<Q>(o);
+				F = conv_svec_small<Q>(cs, gi); // (chained: mantissa and exponent straight from the sums)
 				put_vec<Q>(s, mdc + k - 1, F, sl); // F_k+1
 			}
 		}
@@ -633,9 +665,9 @@ __global__ __launch_bounds__(64) void cn_bp_small_kernel(NblGraphDev g, NblWork 
 			WSYNC();
 			const SVec F = get_vec<Q>(s, (d == 1) ? 0 : mdc + d - 2, sl);
 			emit(lse_conv_small<Q>(F, R, s, sl, gi), d);
-			const double o = lse_conv_small<Q>(R, get_vec<Q>(s, d, sl), s, sl, gi);
-			if (d == 1) emit(o, 0);
-			else R = to_svec<Q>(o);
+			const ConvSum cs = conv_core_small<Q>(R, get_vec<Q>(s, d, sl), s, sl);
+			if (d == 1) emit(conv_log_small<Q>(cs, sl, gi), 0);
+			else R = conv_svec_small<Q>(cs, gi);
 		}
 	}
 }
