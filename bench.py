@@ -159,7 +159,8 @@ def limiter_text():
             valu = pw["valu_busy_of_wave_lifetime_x4_waves"]
             lds = 16.0 * pw["lds_active_cycles"] / pw["wave_cycles"]  # 16 waves of a CU share its LDS port
             return (f"fp64 valu issue ({100 * valu:.0f} % busy) + lds port ({100 * lds:.0f} %), not hbm ({PMC_SUMMARY}: "
-                    f"{pw['valu_insts']:.0f} VALU / {pw['salu_insts']:.0f} SALU / {pw['lds_insts']:.0f} LDS instructions per check-wave)")
+                    f"{pw['valu_insts']:.0f} VALU / {pw['salu_insts']:.0f} SALU / {pw['lds_insts']:.0f} LDS instructions per check-wave); "
+                    "the socket sits at its power limit under this kernel (1.36 kW, shader clock 2.08 of 2.4 GHz: profiles/r03_clocks.txt)")
     return None
 
 
