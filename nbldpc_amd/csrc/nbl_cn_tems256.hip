@@ -244,6 +244,15 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 		constexpr int d = decltype(d_tag)::value, sh = P * (DC - 1 - d); // sh = digit of column d in the path code
 		const double NOPATH = __builtin_nan("");
 		uint64_t cm[NS];
+		// Candidates that cannot matter are left out (nbl_cn_tems64.hip): a path through a deviation of cost u costs at least u, and
+		// check sum s is already reached for best[s] = min(cheapest single deviation, v2[s], v3[s]); u > max_s best[s] neither wins nor ties
+		double reach = 0.0;
+#pragma unroll
+		for (int i = 0; i < NS; i++) {
+			const double m1 = (lane + 64 * i == 0) ? 0.0 : dmin(dmin(u[i][0], u[i][1]), dmin(u[i][2], u[i][3]));
+			reach = dmax(reach, __builtin_fmin(__builtin_fmin(m1, st[i].v2), st[i].v3));
+		}
+		reach = wave_fmax_nonneg(reach);
 #pragma unroll
 		for (int i = 0; i < NS; i++) {
 			const int s = lane + 64 * i;
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 			Sc[s] = make_uint2(st[i].c1, st[i].c2);
 			V3s[s] = st[i].v3; // (what the exact pass starts from, should this column tie)
 			C3s[s] = st[i].c3;
-			cm[i] = __ballot(((mask[i] >> d) & 1) && s > 0);
+			cm[i] = __ballot(((mask[i] >> d) & 1) && s > 0 && u[i][d] <= reach);
 		}
 		__syncthreads();
 		if (nc >= 2) {

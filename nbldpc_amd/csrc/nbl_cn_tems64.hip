@@ -176,6 +176,8 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 	}
 	// ---- 3. min-plus dynamic programme over the columns; v[l], c[l] = best path with exactly l deviating columns -----------
 	const double INF = __builtin_huge_val();
+	// the cheapest single deviation that reaches the lane's check sum (its column has rank 0 there: always marked)
+	const double m1 = (lane == 0) ? 0.0 : dmin(dmin(u[0], u[1]), dmin(u[2], u[3]));
 	int lane8 = lane << 3;
 	asm("" : "+v"(lane8)); // (opaque: otherwise (lane << 3) ^ (q << 3) becomes (lane ^ q) << 3, a second vector instruction per gather)
 	double v1 = INF, v2 = INF, v3 = INF;
@@ -231,7 +233,11 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 		Sc[lane] = make_uint2(c1, c2);
 		__syncthreads();
 		if (nc >= 2) {
-			const uint64_t cm = __ballot(((mask >> d) & 1) && lane > 0);
+			// Candidates that cannot matter are left out: every cost is >= 0, so a path through a deviation of cost u costs at least u,
+			// and check sum s is already reached for best[s] = min(cheapest single deviation m1[s], v2[s], v3[s]) -- a bound that only
+			// falls from here on.  u > max_s best[s] can therefore neither win nor tie anywhere, directly or as a predecessor.
+			const double reach = wave_fmax_nonneg(__builtin_fmin(__builtin_fmin(m1, v2), v3));
+			const uint64_t cm = __ballot(((mask >> d) & 1) && lane > 0 && u[d] <= reach);
 			const double v2s = v2, v3s = v3;
 			const unsigned c2s = c2, c3s = c3;
 			uint64_t tie = 0;
