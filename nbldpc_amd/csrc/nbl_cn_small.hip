@@ -235,6 +235,12 @@ __global__ __launch_bounds__(64, 6) void cn_tems_small_kernel(NblGraphDev g, Nbl
 		if (rank == 1) o1 = d;
 	}
 	if (sl == 0) mask = 0; // symbol 0 = "no deviation" is handled apart
+	// the cheapest single deviation that reaches the lane's check sum (its column has rank 0 there: always marked)
+	double m1 = 0.0;
+	if (sl > 0) {
+		m1 = dU[sl];
+		for (int d = 1; d < dc; d++) m1 = dmin(m1, dU[d * Q + sl]);
+	}
 
 	// ---- 3. min-plus DP over the columns; all deviation-count layers advance together (TEMS_ConstructConf :1892-1944) ----
 	{
@@ -247,8 +253,12 @@ __global__ __launch_bounds__(64, 6) void cn_tems_small_kernel(NblGraphDev g, Nbl
 	WSYNC();
 	for (int d = 0; d < dc; d++) {
 		// the deviation symbols of column d as a bit set of the group (every order gives the same minimum and the same path code)
-		uint64_t cand = gballot<Q>((mask >> d) & 1, c.gi);
 		TState b = A[sl]; // q_d = 0: dU[d][0] = 0 (:1826), cost unchanged
+		// Candidates that cannot matter are left out (nbl_cn_tems64.hip): every cost is >= 0, so a path through a deviation of cost u
+		// costs at least u, and check sum s is already reached for best[s] = min(m1[s], the layers of s so far) -- a bound that only
+		// falls from here on; u > max_s best[s] can neither win nor tie anywhere, directly or as a predecessor.  (nc >= 1 here.)
+		const double reach = gmax_f64<Q>(dmin(dmin(m1, b.v[0]), dmin(b.v[1], dmin(b.v[2], b.v[3]))));
+		uint64_t cand = gballot<Q>(((mask >> d) & 1) && dU[d * Q + sl] <= reach, c.gi);
 #pragma unroll
 		for (int l = 0; l < 4; l++) { b.v[l] = b.v[l] + 0.0; b.c[l] = b.c[l] * Q; }
 		while (cand) {

@@ -236,6 +236,7 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 			// Candidates that cannot matter are left out: every cost is >= 0, so a path through a deviation of cost u costs at least u,
 			// and check sum s is already reached for best[s] = min(cheapest single deviation m1[s], v2[s], v3[s]) -- a bound that only
 			// falls from here on.  u > max_s best[s] can therefore neither win nor tie anywhere, directly or as a predecessor.
+			// (the bound from m1 alone leaves out next to nothing: it is v2 and v3 that bring it down)
 			const double reach = wave_fmax_nonneg(__builtin_fmin(__builtin_fmin(m1, v2), v3));
 			const uint64_t cm = __ballot(((mask >> d) & 1) && lane > 0 && u[d] <= reach);
 			const double v2s = v2, v3s = v3;
