@@ -238,19 +238,25 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 			// falls from here on.  u > max_s best[s] can therefore neither win nor tie anywhere, directly or as a predecessor.
 			// (the bound from m1 alone leaves out next to nothing: it is v2 and v3 that bring it down)
 			const double reach = wave_fmax_nonneg(__builtin_fmin(__builtin_fmin(m1, v2), v3));
-			const uint64_t cm = __ballot(((mask >> d) & 1) && lane > 0 && u[d] <= reach);
+			// ... and per layer: a layer-2 path through this column costs at least u + min v1, a layer-3 path at least u + min v2 (the sums
+			// as the relaxation itself rounds them: rounding is monotone, so every actual value is >= the rounded bound)
+			const bool marked = ((mask >> d) & 1) && lane > 0;
+			const bool both = (d >= 2 && nc >= 3);
+			const double least1 = wave_fmin_nonneg(v1), least2 = both ? wave_fmin_nonneg(v2) : 0.0; // (whole-wave reductions: not inside a lane condition)
+			const uint64_t cm2 = __ballot(marked && u[d] + least1 <= reach);
+			const uint64_t cm3 = both ? (cm2 & __ballot(u[d] + least2 <= reach)) : 0;
 			const double v2s = v2, v3s = v3;
 			const unsigned c2s = c2, c3s = c3;
 			uint64_t tie = 0;
-			if (d >= 2 && nc >= 3) fold(std::false_type{}, true, cm, u[d], sh, tie);
-			else fold(std::false_type{}, false, cm, u[d], sh, tie);
+			if (both) fold(std::false_type{}, true, cm3, u[d], sh, tie);
+			fold(std::false_type{}, false, cm2 & ~cm3, u[d], sh, tie);
 #ifdef NBL_T64_NOTIE
 			tie = 0; // diagnostic (wrong results on ties): never repeat a column
 #endif
 			if (tie) { // equal costs somewhere: the column again, path codes compared (integer-valued LLRs, dead-zone zeros)
 				v2 = v2s; v3 = v3s; c2 = c2s; c3 = c3s;
-				if (d >= 2 && nc >= 3) fold(std::true_type{}, true, cm, u[d], sh, tie);
-				else fold(std::true_type{}, false, cm, u[d], sh, tie);
+				if (both) fold(std::true_type{}, true, cm3, u[d], sh, tie);
+				fold(std::true_type{}, false, cm2 & ~cm3, u[d], sh, tie);
 			}
 		}
 		if (((mask >> d) & 1) && lane > 0) relax(v1, c1, u[d], (unsigned)lane << sh);

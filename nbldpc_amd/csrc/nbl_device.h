@@ -145,6 +145,26 @@ __device__ __forceinline__ double wave_fmax_nonneg(double x)
 	return __hiloint2double((int)mh, (int)ml);
 }
 
+__device__ __forceinline__ unsigned wave_umin_id(unsigned x)
+{
+	constexpr int ID = -1;
+	x = min(x, (unsigned)__builtin_amdgcn_update_dpp(ID, (int)x, 0x111, 0xF, 0xF, false));
+	x = min(x, (unsigned)__builtin_amdgcn_update_dpp(ID, (int)x, 0x112, 0xF, 0xF, false));
+	x = min(x, (unsigned)__builtin_amdgcn_update_dpp(ID, (int)x, 0x114, 0xF, 0xF, false));
+	x = min(x, (unsigned)__builtin_amdgcn_update_dpp(ID, (int)x, 0x118, 0xF, 0xF, false));
+	x = min(x, (unsigned)__builtin_amdgcn_update_dpp(ID, (int)x, 0x142, 0xA, 0xF, false));
+	x = min(x, (unsigned)__builtin_amdgcn_update_dpp(ID, (int)x, 0x143, 0xC, 0xF, false));
+	return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+// Exact wave minimum of non-negative doubles (+inf allowed, no NaN), the same way: high words, then the low words of the lanes that
+// hold the smallest high word.
+__device__ __forceinline__ double wave_fmin_nonneg(double x)
+{
+	const unsigned hi = (unsigned)__double2hiint(x), mh = wave_umin_id(hi);
+	const unsigned lo = (hi == mh) ? (unsigned)__double2loint(x) : 0xffffffffu, ml = wave_umin_id(lo);
+	return __hiloint2double((int)mh, (int)ml);
+}
+
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ double uniform_f64(double v)

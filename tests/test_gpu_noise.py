@@ -172,5 +172,5 @@ def test_integer_wave_maximum_on_the_device(tmp_path):
     subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-I", os.path.join(root, "nbldpc_amd", "csrc"),
                            os.path.join(root, "tests", "wave_reduce_device_check.hip"), "-o", exe])
     r = json.loads(subprocess.check_output([exe], text=True))
-    assert r["rows"] == 200000 and r["differ_from_host"] == 0 and r["differ_from_fp64_reduction"] == 0, r
+    assert r["rows"] == 200000 and r["differ_from_host"] == 0 and r["differ_from_fp64_reduction"] == 0 and r["min_differs_from_host"] == 0, r
 
