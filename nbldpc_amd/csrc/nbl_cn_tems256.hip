@@ -53,7 +53,7 @@ __device__ __forceinline__ double pick(const double (&u)[DC], int k)
 // NC = the deviation budget tems_nc (1..3) as a template parameter: with a run-time nc the layer-3 update sits behind a branch
 // in the candidate loop and the 16-byte predecessor loads are split in two
 template <bool FUSED, int NC>
-__global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
+__global__ __launch_bounds__(64, 4) void cn_tems_q256_dc4_kernel(NblGraphDev g, NblWork w, NblRun r)
 {
 	// One 10 KB region, used in two phases (sixteen waves per CU = four per SIMD; the register count allows as many):
 	//   programme:  predecessor state Sv1 | Sv2 (2 KB each: costs of layers 1, 2) | Sc (2 KB: 8-byte code pairs) -- three arrays of
@@ -246,13 +246,21 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 		uint64_t cm[NS];
 		// Candidates that cannot matter are left out (nbl_cn_tems64.hip): a path through a deviation of cost u costs at least u, and
 		// check sum s is already reached for best[s] = min(cheapest single deviation, v2[s], v3[s]); u > max_s best[s] neither wins nor ties
-		double reach = 0.0;
+		// -- and per layer: a layer-2 path through this column costs at least u + min v1, a layer-3 path at least u + min v2 (the sums as
+		// the relaxation itself rounds them: rounding is monotone, so every actual value is >= the rounded bound)
+		constexpr bool both = (d >= 2 && nc >= 3);
+		double reach = 0.0, least1 = INF, least2 = INF;
 #pragma unroll
 		for (int i = 0; i < NS; i++) {
 			const double m1 = (lane + 64 * i == 0) ? 0.0 : dmin(dmin(u[i][0], u[i][1]), dmin(u[i][2], u[i][3]));
 			reach = dmax(reach, __builtin_fmin(__builtin_fmin(m1, st[i].v2), st[i].v3));
+			least1 = dmin(least1, st[i].v1);
+			least2 = dmin(least2, st[i].v2);
 		}
 		reach = wave_fmax_nonneg(reach);
+		least1 = wave_fmin_nonneg(least1);
+		least2 = both ? wave_fmin_nonneg(least2) : 0.0;
+		uint64_t cm3[NS];
 #pragma unroll
 		for (int i = 0; i < NS; i++) {
 			const int s = lane + 64 * i;
@@ -261,13 +269,15 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 			Sc[s] = make_uint2(st[i].c1, st[i].c2);
 			V3s[s] = st[i].v3; // (what the exact pass starts from, should this column tie)
 			C3s[s] = st[i].c3;
-			cm[i] = __ballot(((mask[i] >> d) & 1) && s > 0 && u[i][d] <= reach);
+			cm[i] = __ballot(((mask[i] >> d) & 1) && s > 0 && u[i][d] + least1 <= reach);
+			cm3[i] = both ? (cm[i] & __ballot(u[i][d] + least2 <= reach)) : 0;
+			cm[i] &= ~cm3[i]; // layer 2 only
 		}
 		__syncthreads();
 		if (nc >= 2) {
 			uint64_t tie = 0;
-			constexpr bool both = (d >= 2 && nc >= 3);
-			fold(std::false_type{}, std::integral_constant<bool, both>{}, std::integral_constant<int, d>{}, cm[0], cm[1], cm[2], cm[3], tie);
+			if (both) fold(std::false_type{}, std::true_type{}, std::integral_constant<int, d>{}, cm3[0], cm3[1], cm3[2], cm3[3], tie);
+			fold(std::false_type{}, std::false_type{}, std::integral_constant<int, d>{}, cm[0], cm[1], cm[2], cm[3], tie);
 			if (tie) { // equal costs somewhere: the column again from its start, path codes compared
 #pragma unroll
 				for (int i = 0; i < NS; i++) {
@@ -278,7 +288,8 @@ __global__ __launch_bounds__(64) void cn_tems_q256_dc4_kernel(NblGraphDev g, Nbl
 					st[i].v3 = V3s[s];
 					st[i].c3 = C3s[s];
 				}
-				fold(std::true_type{}, std::integral_constant<bool, both>{}, std::integral_constant<int, d>{}, cm[0], cm[1], cm[2], cm[3], tie);
+				if (both) fold(std::true_type{}, std::true_type{}, std::integral_constant<int, d>{}, cm3[0], cm3[1], cm3[2], cm3[3], tie);
+				fold(std::true_type{}, std::false_type{}, std::integral_constant<int, d>{}, cm[0], cm[1], cm[2], cm[3], tie);
 			}
 		}
 #pragma unroll
