@@ -23,6 +23,9 @@
 //     entry and one address per entry serve three convolutions).
 //   * 8 KB LDS per wave at nm = 32 (three q-vectors + the lists), four waves per SIMD (VGPR-limited).
 #include <hip/hip_runtime.h>
+#ifndef NBL_EMS_PRUNE
+#define NBL_EMS_PRUNE 1 // the exact bound on the gather lists (0: every entry, for A/B runs)
+#endif
 #include <type_traits>
 #include "nbl_device.h"
 #include "nbl_kernels.h"
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		}
 	};
 	// NP max-plus gather convolutions over ONE list: acc[p][s] = max_k  P_p[s ^ t_k] + v_k, P_p = B0 + p * Q
-	auto gather_conv = [&](int jc, auto np_tag, double (&acc)[decltype(np_tag)::value][4]) {
+	auto gather_conv = [&](int jc, auto np_tag, double (&acc)[decltype(np_tag)::value][4], uint64_t keep) {
 		constexpr int NP = decltype(np_tag)::value;
 		constexpr int UN = 4; // entries per trip (twelve 16-byte gathers in flight in the three-way loop)
 		const char *Pb = (const char *)B0;
@@ -707,6 +710,22 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			e.t8 = 0;
 			return e;
 		};
+#if NBL_EMS_PRUNE
+		// entries k0 .. k1-1 of the list that `keep` has not ruled out (see the bound in front of the gathers), UN per trip
+		auto run = [&](int k0, int k1, auto swapped, auto upper) {
+			uint64_t m = keep & ((k1 >= 64 ? ~0ull : (1ull << k1) - 1ull) & ~((1ull << k0) - 1ull));
+			int left = __builtin_popcountll(m);
+			for (; left >= UN; left -= UN) {
+				STAMP_COUNT(11);
+				ListEnt en[UN];
+#pragma unroll
+				for (int u = 0; u < UN; u++) { en[u] = entry(__builtin_ctzll(m)); m &= m - 1; }
+#pragma unroll
+				for (int u = 0; u < UN; u++) body(en[u], swapped, upper);
+			}
+			for (; left > 0; left--) { STAMP_COUNT(12); body(entry(__builtin_ctzll(m)), swapped, upper); m &= m - 1; }
+		};
+#else
 		auto run = [&](int k0, int k1, auto swapped, auto upper) {
 			int k = k0;
 			for (; k + UN <= k1; k += UN) {
@@ -719,6 +738,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			}
 			for (; k < k1; k++) { STAMP_COUNT(12); body(entry(k), swapped, upper); }
 		};
+#endif
 		run(0, nA[jc], std::false_type{}, std::false_type{});
 		run(nA[jc], n0[jc], std::false_type{}, std::true_type{});
 		run(n0[jc], nC[jc], std::true_type{}, std::false_type{});
@@ -779,8 +799,38 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			double a3[1][4], a210[3][4];
 #pragma unroll
 			for (int i = 0; i < 4; i++) { a3[0][i] = S[3][i]; a210[0][i] = S[2][i]; a210[1][i] = S[1][i]; a210[2][i] = S[0][i]; }
-			gather_conv(2, std::integral_constant<int, 1>{}, a3);
-			gather_conv(3, std::integral_constant<int, 3>{}, a210);
+			uint64_t keep2 = ~0ull, keep3 = ~0ull;
+#if NBL_EMS_PRUNE
+			// Entries of the gather lists that cannot change any output are left out -- exactly.  Output x already holds conf(q,1), so
+			// S[x][s] >= floor_x = min_s S[x][s] for every s.  A plane value that does not come from the pair (rank 0, rank 0) is at most
+			// P2 = max(fl(m_a + sec_b), fl(sec_a + m_b)), sec = the best list value beside rank 0; so entry k of the gather list adds at most
+			// fl(P2 + v_k) through such a pair (rounding is monotone) -- and through the pair (rank 0, rank 0) it adds the one-deviation
+			// configuration (m_a + m_b) + v_k, the very sum conf(q,1) has already formed for that symbol.  fl(P2 + v_k) < floor_x for every
+			// output the list serves => the entry changes nothing.  The bounds are taken on float keys and widened by more than the
+			// rounding (a looser bound only keeps more); converged frames -- one dominant symbol per edge -- lose almost every entry.
+			{
+				double flo[4], sec[3];
+#pragma unroll
+				for (int x = 0; x < 4; x++) {
+					const double lf = (double)unkey32(wave_min_i32(key32(dmin(dmin(S[x][0], S[x][1]), dmin(S[x][2], S[x][3])))));
+					flo[x] = (lf - __builtin_fabs(lf) * 0x1p-22) - 0x1p-120;
+				}
+#pragma unroll
+				for (int j = 0; j < 3; j++) {
+					const ListEnt e = list_at(j, lane & (NM - 1));
+					const double sf = (double)unkey32(wave_max_i32(key32((e.t8 == (ztop[j] << 3)) ? NBL_NEG_INF : e.v)));
+					sec[j] = (sf == NBL_NEG_INF) ? sf : (sf + __builtin_fabs(sf) * 0x1p-22) + 0x1p-120;
+				}
+				const double p01 = dmax(mtop[0] + sec[1], sec[0] + mtop[1]), p02 = dmax(mtop[0] + sec[2], sec[0] + mtop[2]),
+				             p12 = dmax(mtop[1] + sec[2], sec[1] + mtop[2]);
+				const double v2 = lstv[2 * NM + (lane & (NM - 1))], v3 = lstv[3 * NM + (lane & (NM - 1))];
+				const uint64_t live = (nmr >= 64) ? ~0ull : (1ull << nmr) - 1ull;
+				keep2 = __ballot(!(p01 + v2 < flo[3])) & live;
+				keep3 = __ballot(!(p01 + v3 < flo[2]) || !(p02 + v3 < flo[1]) || !(p12 + v3 < flo[0])) & live;
+			}
+#endif
+			gather_conv(2, std::integral_constant<int, 1>{}, a3, keep2);
+			gather_conv(3, std::integral_constant<int, 3>{}, a210, keep3);
 #pragma unroll
 			for (int i = 0; i < 4; i++) { S[3][i] = a3[0][i]; S[2][i] = a210[0][i]; S[1][i] = a210[1][i]; S[0][i] = a210[2][i]; }
 		}
