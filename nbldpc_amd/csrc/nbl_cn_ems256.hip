@@ -415,6 +415,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 
 	// ---- rank 0 of every edge: value m_j, check-domain symbol z_j (highest symbol among equal maxima, :1731) -------
 	double mtop[4], lmin[4];
+	double sec[4] = {0, 0, 0, 0}; // an upper bound of the best value beside rank 0 (for the bounds in front of the gathers)
 	int ztop[4];
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
@@ -436,6 +437,19 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		const unsigned twl = (unsigned)__builtin_amdgcn_readlane((int)toff[j].x, tl), twh = (unsigned)__builtin_amdgcn_readlane((int)toff[j].y, tl);
 		const unsigned tw = (topa & 128) ? twh : twl;
 		ztop[j] = (int)((tw >> (16 * (topa & 1))) & 0xffffu) >> 3;
+#if NBL_EMS_PRUNE
+		if (NC >= 3) {
+			// the best value beside rank 0: every lane's maximum, the lane that holds rank 0 with that slot left out; on float keys,
+			// rounded up by more than the rounding (an upper bound is all the pruning needs)
+			const int ts = (topa & 1) + 2 * (topa >> 7); // slot of rank 0 (wave-uniform)
+			// (selects, not v[j][ts]: a run-time index would put the vector into scratch memory)
+			const double mate = (ts == 0) ? v[j][1] : (ts == 1) ? v[j][0] : (ts == 2) ? v[j][3] : v[j][2]; // the other value of rank 0's 16-byte pair
+			const double far = (ts & 2) ? dmax(v[j][0], v[j][1]) : dmax(v[j][2], v[j][3]);                 // the other pair
+			const double loc2 = (lane == tl) ? dmax(mate, far) : loc;
+			const double sf = (double)unkey32(wave_max_i32(key32(loc2)));
+			sec[j] = uniform_f64((sf + __builtin_fabs(sf) * 0x1p-22) + 0x1p-120);
+		}
+#endif
 	}
 	STAMP(1);
 
@@ -803,23 +817,17 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 #if NBL_EMS_PRUNE
 			// Entries of the gather lists that cannot change any output are left out -- exactly.  Output x already holds conf(q,1), so
 			// S[x][s] >= floor_x = min_s S[x][s] for every s.  A plane value that does not come from the pair (rank 0, rank 0) is at most
-			// P2 = max(fl(m_a + sec_b), fl(sec_a + m_b)), sec = the best list value beside rank 0; so entry k of the gather list adds at most
+			// P2 = max(fl(m_a + sec_b), fl(sec_a + m_b)), sec = the best value of the edge beside rank 0 (found with rank 0, above); so entry k of the gather list adds at most
 			// fl(P2 + v_k) through such a pair (rounding is monotone) -- and through the pair (rank 0, rank 0) it adds the one-deviation
 			// configuration (m_a + m_b) + v_k, the very sum conf(q,1) has already formed for that symbol.  fl(P2 + v_k) < floor_x for every
 			// output the list serves => the entry changes nothing.  The bounds are taken on float keys and widened by more than the
 			// rounding (a looser bound only keeps more); converged frames -- one dominant symbol per edge -- lose almost every entry.
 			{
-				double flo[4], sec[3];
+				double flo[4];
 #pragma unroll
 				for (int x = 0; x < 4; x++) {
 					const double lf = (double)unkey32(wave_min_i32(key32(dmin(dmin(S[x][0], S[x][1]), dmin(S[x][2], S[x][3])))));
 					flo[x] = (lf - __builtin_fabs(lf) * 0x1p-22) - 0x1p-120;
-				}
-#pragma unroll
-				for (int j = 0; j < 3; j++) {
-					const ListEnt e = list_at(j, lane & (NM - 1));
-					const double sf = (double)unkey32(wave_max_i32(key32((e.t8 == (ztop[j] << 3)) ? NBL_NEG_INF : e.v)));
-					sec[j] = (sf == NBL_NEG_INF) ? sf : (sf + __builtin_fabs(sf) * 0x1p-22) + 0x1p-120;
 				}
 				const double p01 = dmax(mtop[0] + sec[1], sec[0] + mtop[1]), p02 = dmax(mtop[0] + sec[2], sec[0] + mtop[2]),
 				             p12 = dmax(mtop[1] + sec[2], sec[1] + mtop[2]);
