@@ -285,6 +285,14 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	const int m = xs.unit, b = nbl_codeword(w, r, xs.slot);
 	if (b < 0) return;
 	if (!r.fixed_iters && w.done[b]) return;
+#if NBL_EMS_PRUNE
+	// A codeword whose syndrome has been zero keeps iterating in fixed-iteration runs; its vectors have one dominant symbol each,
+	// which is where the short lists below pay (they are exact for any input -- the flag only decides whether the bounds are worth
+	// forming: on a codeword that is still searching they leave out next to nothing).
+	const bool tryf = NC >= 3 && r.fixed_iters && w.done[b];
+#else
+	const bool tryf = false;
+#endif
 	const int c0 = g.coff[m];
 
 	// three q-vectors: staging of the incoming vectors | histogram (B0..B1) | the three pair convolutions | staging of the outputs
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		const unsigned tw = (topa & 128) ? twh : twl;
 		ztop[j] = (int)((tw >> (16 * (topa & 1))) & 0xffffu) >> 3;
 #if NBL_EMS_PRUNE
-		if (NC >= 3) {
+		if (tryf) {
 			// the best value beside rank 0: every lane's maximum, the lane that holds rank 0 with that slot left out; on float keys,
 			// rounded up by more than the rounding (an upper bound is all the pruning needs)
 			const int ts = (topa & 1) + 2 * (topa >> 7); // slot of rank 0 (wave-uniform)
@@ -507,92 +515,53 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	// list layout per edge: the members of slot 0, of slot 2 (even symbols, bit 7 clear / set), of slot 1, of slot 3 (odd symbols);
 	// nA = end of the slot-0 run, n0 = end of the even symbols, nC = end of the slot-1 run
 	int n0[4] = {0, 0, 0, 0}, nA[4] = {0, 0, 0, 0}, nC[4] = {0, 0, 0, 0};
+	int cntl[4] = {nmr, nmr, nmr, nmr}; // entries per list
+	// Short lists (NC >= 3).  Output x already holds conf(q,1): S[x][s] >= flo[x] for every s.  A configuration for output x that
+	// conf(q,1) does not already contain has two or more deviating edges, so beside any one of its entries (value v, edge a) the other
+	// two edges b, c contribute at most p_bc = max(m_b + sec_c, sec_b + m_c) (sec = best value beside rank 0): its sum is at most
+	// v + p_bc, up to rounding.  An entry with v + p_bc < flo[x] for every output x != a therefore cannot change anything, in any
+	// role (pair operand or gather entry): thr[a] = min_x (flo[x] - p_bc), lowered by far more than the rounding of the sums.  When
+	// the entries at or above their thresholds number <= nm on all four edges, they ARE the useful part of the top-nm lists: the lists
+	// are built from one compare per symbol, without histogram and cut search, and every later loop runs over the short lists.  On a
+	// converged codeword (one dominant symbol per edge) that leaves a handful of entries.  Otherwise the full selection runs as before.
+	bool fast = false;
+	double thr[4] = {0, 0, 0, 0};
+#if NBL_EMS_PRUNE
+	if (tryf) {
+		double flo[4]; // lower bounds of min_s S[x][s]
+#pragma unroll
+		for (int x = 0; x < 4; x++) {
+			const double lf = (double)unkey32(wave_min_i32(key32(dmin(dmin(S[x][0], S[x][1]), dmin(S[x][2], S[x][3])))));
+			flo[x] = uniform_f64((lf - __builtin_fabs(lf) * 0x1p-22) - 0x1p-120);
+		}
+		auto pb = [&](int b, int c) { return dmax(mtop[b] + sec[c], sec[b] + mtop[c]); };
+		const double p01 = pb(0, 1), p02 = pb(0, 2), p03 = pb(0, 3), p12 = pb(1, 2), p13 = pb(1, 3), p23 = pb(2, 3);
+		auto low = [&](double f, double p) { // f - p, lowered
+			const double t = f - p;
+			return (t - (__builtin_fabs(f) + __builtin_fabs(p)) * 0x1p-40) - 0x1p-100;
+		};
+		thr[0] = uniform_f64(dmin(dmin(low(flo[1], p23), low(flo[2], p13)), low(flo[3], p12)));
+		thr[1] = uniform_f64(dmin(dmin(low(flo[0], p23), low(flo[2], p03)), low(flo[3], p02)));
+		thr[2] = uniform_f64(dmin(dmin(low(flo[0], p13), low(flo[1], p03)), low(flo[3], p01)));
+		thr[3] = uniform_f64(dmin(dmin(low(flo[0], p12), low(flo[1], p02)), low(flo[2], p01)));
+		fast = true;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			int c = 0;
+#pragma unroll
+			for (int i = 0; i < 4; i++) c += __popcll(__ballot(!(v[j][i] < thr[j]))); // (the masks themselves are formed again at the compaction: 64 scalar registers otherwise)
+			cntl[j] = c;
+			fast = fast && c <= nmr;
+		}
+		if (!fast) cntl[0] = cntl[1] = cntl[2] = cntl[3] = nmr;
+#ifdef NBL_EMS_STAMPS
+		if (st_on) { st_acc[13] += fast ? 1 : 0; st_acc[14] += cntl[0] + cntl[1] + cntl[2] + cntl[3]; } // short-list checks, list entries
+#endif
+	}
+#endif
 	if (NC >= 2) { // conf(nm,1) needs no lists: it is contained in conf(q,1)
-		int bk[4][4];
-		int *H = (int *)B0; // [4 edges][256 buckets] (spans B0 and B1); lane l reads buckets 4l .. 4l+3 of every edge
-		int one;            // the increment of the sixteen histogram atomics, held in ONE register (hipcc re-materialises a literal 1 per atomic)
-		asm volatile("v_mov_b32 %0, 1" : "=v"(one));
-		WSYNC();
-		{
-			int4 z4 = {0, 0, 0, 0};
-#pragma unroll
-			for (int i = 0; i < 4; i++) ((int4 *)H)[i * 64 + lane] = z4;
-		}
-		WSYNC();
-#pragma unroll
-		for (int j = 0; j < 4; j++) {
-			// bucketing only has to be monotone and the same in every lane: the hardware reciprocal will do (an IEEE division is
-			// ~14 instructions).  lmin lies strictly below every lane maximum, so range > 0, entries >= the smallest lane maximum land
-			// in buckets 0..255 and everything below lmin is clamped to 256 = "not counted"
-			const double scale = 256.0 * __builtin_amdgcn_rcp(mtop[j] - lmin[j]);
-#pragma unroll
-			for (int i = 0; i < 4; i++) {
-				// v_cvt_i32_f64 saturates (and maps NaN to 0): no FP64 minimum against a constant that would have to be materialised in
-				// a register pair.  A bucket >= 256 lies below the lower bound and is not counted; every later use compares bk against
-				// a bucket <= 255, so it needs no clamp either
-				int bi;
-				asm("v_cvt_i32_f64 %0, %1" : "=v"(bi) : "v"((mtop[j] - v[j][i]) * scale));
-				bk[j][i] = bi;
-				if (bi < 256) __hip_atomic_fetch_add(&H[j * 256 + bi], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			}
-		}
-		WSYNC();
-		int hc[4][4]; // [bucket slot of this lane][edge]
-#pragma unroll
-		for (int j = 0; j < 4; j++) {
-			const int4 h4 = ((int4 *)H)[j * 64 + lane];
-			hc[0][j] = h4.x; hc[1][j] = h4.y; hc[2][j] = h4.z; hc[3][j] = h4.w;
-		}
-		STAMP(2);
-		// list entry fields of the lane's four slots: symbol and gather offset are the same for every edge
-		int2 tt2[4];
-#pragma unroll
-		for (int i = 0; i < 4; i++) { tt2[i].x = sym_of(lane, i) << 3; tt2[i].y = (sym_of(lane, i) & 0x7E) << 3; }
-		if (VARNM) { // list entries beyond the nm selected ones: value -inf, pairwise different symbols (a scatter of several lanes
-			// to ONE address is serialised by the LDS)
-			WSYNC();
-#pragma unroll
-			for (int j = 0; j < 4; j++) {
-				lstv[j * NM + (lane & (NM - 1))] = NBL_NEG_INF;
-				lstt[j * NM + (lane & (NM - 1))] = make_int2((lane & (NM - 1)) << 3, 0);
-			}
-			WSYNC();
-		}
-		// per edge: locate the cut bucket, settle the members, compact them into the list image
-		// [even-symbol group | odd-symbol group]
-#pragma unroll
-		for (int j = 0; j < 4; j++) {
-			const int tot = hc[0][j] + hc[1][j] + hc[2][j] + hc[3][j];
-			const int cum = wave_scan_add(tot);
-			const uint64_t reach = __ballot(cum >= nmr);
-			const int lstar = reach ? __builtin_ctzll(reach) : 63;
-			// the cut lane's four bucket counts and its running total: which of its buckets holds the nm-th entry is scalar work
-			const int cl = __builtin_amdgcn_readlane(cum, lstar);
-			const int q1 = __builtin_amdgcn_readlane(hc[1][j], lstar),
-			          q2 = __builtin_amdgcn_readlane(hc[2][j], lstar), q3 = __builtin_amdgcn_readlane(hc[3][j], lstar);
-			const int s0 = cl - q3 - q2 - q1, s1 = cl - q3 - q2, s2 = cl - q3;
-			const int bsel = (s0 >= nmr) ? 0 : (s1 >= nmr) ? 1 : (s2 >= nmr) ? 2 : 3;
-			const int upto = (s0 >= nmr) ? s0 : (s1 >= nmr) ? s1 : (s2 >= nmr) ? s2 : cl; // entries up to and including the cut bucket
-			const int bstar = 4 * lstar + bsel;
-			const bool exact = reach && upto == nmr; // the cut bucket ends exactly at the nm-th entry
-			uint64_t member[4];
-			if (exact) {
-#pragma unroll
-				for (int i = 0; i < 4; i++) member[i] = __ballot(bk[j][i] <= bstar);
-			} else {
-				// (no bucket reaches nm -- cannot happen with finite inputs: every entry is a candidate)
-				STAMP_COUNT(10);
-				SelState ss;
-#pragma unroll
-				for (int i = 0; i < 4; i++) { ss.cand[i] = reach ? __ballot(bk[j][i] == bstar) : ~0ull; ss.gt[i] = ss.eq[i] = 0; }
-				ss.done = 0;
-				for (int guard = 0; guard < 300 && !ss.done; guard++) {
-					select_step(v[j], nmr, ss);
-					STAMP_COUNT(9);
-				}
-				finish_members(ss, nmr, member, g.c_hinv[c0 + j], g.poly, lane);
-			}
-			// compaction straight from the (wave-uniform) member masks: slots 0, 2 hold even symbols, slots 1, 3 odd ones
+		// list members (wave-uniform masks per slot) -> the list image: slots 0, 2 hold even symbols, slots 1, 3 odd ones
+		auto compact = [&](int j, const uint64_t (&member)[4]) {
 			const int c0n = __popcll(member[0]), c2n = __popcll(member[2]), c1n = __popcll(member[1]);
 			const int ne = c0n + c2n;
 			n0[j] = ne;
@@ -603,9 +572,103 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			for (int i = 0; i < 4; i++) {
 				const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(member[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)member[i], base[i]));
 				if (__builtin_amdgcn_inverse_ballot_w64(member[i])) {
+					// list entry fields of the lane's slot: symbol and gather offset (formed here: two more registers per slot would be
+					// live across the whole selection otherwise)
 					lstv[pos] = v[j][i];
-					lstt[pos] = tt2[i];
+					lstt[pos] = make_int2(sym_of(lane, i) << 3, (sym_of(lane, i) & 0x7E) << 3);
 				}
+			}
+		};
+		if (VARNM || fast) { // list entries beyond the nm selected ones (run-time nm, short lists): value -inf, pairwise different symbols (a scatter of several lanes
+			// to ONE address is serialised by the LDS)
+			WSYNC();
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				lstv[j * NM + (lane & (NM - 1))] = NBL_NEG_INF;
+				lstt[j * NM + (lane & (NM - 1))] = make_int2((lane & (NM - 1)) << 3, 0);
+			}
+			WSYNC();
+		}
+		if (fast) {
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				uint64_t member[4];
+#pragma unroll
+				for (int i = 0; i < 4; i++) member[i] = __ballot(!(v[j][i] < thr[j]));
+				compact(j, member);
+			}
+		} else {
+			int bk[4][4];
+			int *H = (int *)B0; // [4 edges][256 buckets] (spans B0 and B1); lane l reads buckets 4l .. 4l+3 of every edge
+			int one;            // the increment of the sixteen histogram atomics, held in ONE register (hipcc re-materialises a literal 1 per atomic)
+			asm volatile("v_mov_b32 %0, 1" : "=v"(one));
+			WSYNC();
+			{
+				int4 z4 = {0, 0, 0, 0};
+#pragma unroll
+				for (int i = 0; i < 4; i++) ((int4 *)H)[i * 64 + lane] = z4;
+			}
+			WSYNC();
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				// bucketing only has to be monotone and the same in every lane: the hardware reciprocal will do (an IEEE division is
+				// ~14 instructions).  lmin lies strictly below every lane maximum, so range > 0, entries >= the smallest lane maximum land
+				// in buckets 0..255 and everything below lmin is clamped to 256 = "not counted"
+				const double scale = 256.0 * __builtin_amdgcn_rcp(mtop[j] - lmin[j]);
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					// v_cvt_i32_f64 saturates (and maps NaN to 0): no FP64 minimum against a constant that would have to be materialised in
+					// a register pair.  A bucket >= 256 lies below the lower bound and is not counted; every later use compares bk against
+					// a bucket <= 255, so it needs no clamp either
+					int bi;
+					asm("v_cvt_i32_f64 %0, %1" : "=v"(bi) : "v"((mtop[j] - v[j][i]) * scale));
+					bk[j][i] = bi;
+					if (bi < 256) __hip_atomic_fetch_add(&H[j * 256 + bi], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			}
+			WSYNC();
+			int hc[4][4]; // [bucket slot of this lane][edge]
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const int4 h4 = ((int4 *)H)[j * 64 + lane];
+				hc[0][j] = h4.x; hc[1][j] = h4.y; hc[2][j] = h4.z; hc[3][j] = h4.w;
+			}
+			STAMP(2);
+			// per edge: locate the cut bucket, settle the members, compact them into the list image
+			// [even-symbol group | odd-symbol group]
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				uint64_t member[4];
+				const int tot = hc[0][j] + hc[1][j] + hc[2][j] + hc[3][j];
+				const int cum = wave_scan_add(tot);
+				const uint64_t reach = __ballot(cum >= nmr);
+				const int lstar = reach ? __builtin_ctzll(reach) : 63;
+				// the cut lane's four bucket counts and its running total: which of its buckets holds the nm-th entry is scalar work
+				const int cl = __builtin_amdgcn_readlane(cum, lstar);
+				const int q1 = __builtin_amdgcn_readlane(hc[1][j], lstar),
+				          q2 = __builtin_amdgcn_readlane(hc[2][j], lstar), q3 = __builtin_amdgcn_readlane(hc[3][j], lstar);
+				const int s0 = cl - q3 - q2 - q1, s1 = cl - q3 - q2, s2 = cl - q3;
+				const int bsel = (s0 >= nmr) ? 0 : (s1 >= nmr) ? 1 : (s2 >= nmr) ? 2 : 3;
+				const int upto = (s0 >= nmr) ? s0 : (s1 >= nmr) ? s1 : (s2 >= nmr) ? s2 : cl; // entries up to and including the cut bucket
+				const int bstar = 4 * lstar + bsel;
+				const bool exact = reach && upto == nmr; // the cut bucket ends exactly at the nm-th entry
+				if (exact) {
+#pragma unroll
+					for (int i = 0; i < 4; i++) member[i] = __ballot(bk[j][i] <= bstar);
+				} else {
+					// (no bucket reaches nm -- cannot happen with finite inputs: every entry is a candidate)
+					STAMP_COUNT(10);
+					SelState ss;
+#pragma unroll
+					for (int i = 0; i < 4; i++) { ss.cand[i] = reach ? __ballot(bk[j][i] == bstar) : ~0ull; ss.gt[i] = ss.eq[i] = 0; }
+					ss.done = 0;
+					for (int guard = 0; guard < 300 && !ss.done; guard++) {
+						select_step(v[j], nmr, ss);
+						STAMP_COUNT(9);
+					}
+					finish_members(ss, nmr, member, g.c_hinv[c0 + j], g.poly, lane);
+				}
+				compact(j, member);
 			}
 		}
 	}
@@ -672,7 +735,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		}
 	};
 	// NP max-plus gather convolutions over ONE list: acc[p][s] = max_k  P_p[s ^ t_k] + v_k, P_p = B0 + p * Q
-	auto gather_conv = [&](int jc, auto np_tag, double (&acc)[decltype(np_tag)::value][4], uint64_t keep) {
+	auto gather_conv = [&](int jc, auto np_tag, double (&acc)[decltype(np_tag)::value][4]) {
 		constexpr int NP = decltype(np_tag)::value;
 		constexpr int UN = 4; // entries per trip (twelve 16-byte gathers in flight in the three-way loop)
 		const char *Pb = (const char *)B0;
@@ -724,22 +787,6 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			e.t8 = 0;
 			return e;
 		};
-#if NBL_EMS_PRUNE
-		// entries k0 .. k1-1 of the list that `keep` has not ruled out (see the bound in front of the gathers), UN per trip
-		auto run = [&](int k0, int k1, auto swapped, auto upper) {
-			uint64_t m = keep & ((k1 >= 64 ? ~0ull : (1ull << k1) - 1ull) & ~((1ull << k0) - 1ull));
-			int left = __builtin_popcountll(m);
-			for (; left >= UN; left -= UN) {
-				STAMP_COUNT(11);
-				ListEnt en[UN];
-#pragma unroll
-				for (int u = 0; u < UN; u++) { en[u] = entry(__builtin_ctzll(m)); m &= m - 1; }
-#pragma unroll
-				for (int u = 0; u < UN; u++) body(en[u], swapped, upper);
-			}
-			for (; left > 0; left--) { STAMP_COUNT(12); body(entry(__builtin_ctzll(m)), swapped, upper); m &= m - 1; }
-		};
-#else
 		auto run = [&](int k0, int k1, auto swapped, auto upper) {
 			int k = k0;
 			for (; k + UN <= k1; k += UN) {
@@ -752,11 +799,10 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			}
 			for (; k < k1; k++) { STAMP_COUNT(12); body(entry(k), swapped, upper); }
 		};
-#endif
 		run(0, nA[jc], std::false_type{}, std::false_type{});
 		run(nA[jc], n0[jc], std::false_type{}, std::true_type{});
 		run(n0[jc], nC[jc], std::true_type{}, std::false_type{});
-		run(nC[jc], nmr, std::true_type{}, std::true_type{});
+		run(nC[jc], cntl[jc], std::true_type{}, std::true_type{});
 	};
 	// c2v[a] = shape(S[h_x a] - S[0]) (:899-916): the output goes back to the variable domain through LDS
 	auto emit_stage = [&](int x, double *Sx) {
@@ -788,6 +834,15 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			for (int i = 0; i < 6; i++) ((double2 *)B0)[i * 64 + lane] = ninf;
 			const ListEnt ea0 = list_at(0, apos), ea1 = list_at(1, apos);
 			WSYNC();
+			if (fast) { // short lists: the moving operands stop at the last entry of the longer one (beyond a list's end: -inf entries)
+				const int mc = cntl[1] > cntl[2] ? cntl[1] : cntl[2];
+				for (int it = 0; it < ((mc + PER - 1) >> (6 - LOGNM)); it++) {
+					const ListEnt eb1 = list_at(1, it * PER + (lane >> LOGNM)), eb2 = list_at(2, it * PER + (lane >> LOGNM));
+					__hip_atomic_fetch_max((double *)((char *)B0 + (ea0.t8 ^ eb1.t8)), ea0.v + eb1.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					__hip_atomic_fetch_max((double *)((char *)B1 + (ea0.t8 ^ eb2.t8)), ea0.v + eb2.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					__hip_atomic_fetch_max((double *)((char *)B2 + (ea1.t8 ^ eb2.t8)), ea1.v + eb2.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			} else
 #pragma unroll
 			for (int it = 0; it < rounds; it++) {
 				const ListEnt eb1 = list_at(1, it * PER + (lane >> LOGNM)), eb2 = list_at(2, it * PER + (lane >> LOGNM));
@@ -813,32 +868,8 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 			double a3[1][4], a210[3][4];
 #pragma unroll
 			for (int i = 0; i < 4; i++) { a3[0][i] = S[3][i]; a210[0][i] = S[2][i]; a210[1][i] = S[1][i]; a210[2][i] = S[0][i]; }
-			uint64_t keep2 = ~0ull, keep3 = ~0ull;
-#if NBL_EMS_PRUNE
-			// Entries of the gather lists that cannot change any output are left out -- exactly.  Output x already holds conf(q,1), so
-			// S[x][s] >= floor_x = min_s S[x][s] for every s.  A plane value that does not come from the pair (rank 0, rank 0) is at most
-			// P2 = max(fl(m_a + sec_b), fl(sec_a + m_b)), sec = the best value of the edge beside rank 0 (found with rank 0, above); so entry k of the gather list adds at most
-			// fl(P2 + v_k) through such a pair (rounding is monotone) -- and through the pair (rank 0, rank 0) it adds the one-deviation
-			// configuration (m_a + m_b) + v_k, the very sum conf(q,1) has already formed for that symbol.  fl(P2 + v_k) < floor_x for every
-			// output the list serves => the entry changes nothing.  The bounds are taken on float keys and widened by more than the
-			// rounding (a looser bound only keeps more); converged frames -- one dominant symbol per edge -- lose almost every entry.
-			{
-				double flo[4];
-#pragma unroll
-				for (int x = 0; x < 4; x++) {
-					const double lf = (double)unkey32(wave_min_i32(key32(dmin(dmin(S[x][0], S[x][1]), dmin(S[x][2], S[x][3])))));
-					flo[x] = (lf - __builtin_fabs(lf) * 0x1p-22) - 0x1p-120;
-				}
-				const double p01 = dmax(mtop[0] + sec[1], sec[0] + mtop[1]), p02 = dmax(mtop[0] + sec[2], sec[0] + mtop[2]),
-				             p12 = dmax(mtop[1] + sec[2], sec[1] + mtop[2]);
-				const double v2 = lstv[2 * NM + (lane & (NM - 1))], v3 = lstv[3 * NM + (lane & (NM - 1))];
-				const uint64_t live = (nmr >= 64) ? ~0ull : (1ull << nmr) - 1ull;
-				keep2 = __ballot(!(p01 + v2 < flo[3])) & live;
-				keep3 = __ballot(!(p01 + v3 < flo[2]) || !(p02 + v3 < flo[1]) || !(p12 + v3 < flo[0])) & live;
-			}
-#endif
-			gather_conv(2, std::integral_constant<int, 1>{}, a3, keep2);
-			gather_conv(3, std::integral_constant<int, 3>{}, a210, keep3);
+			gather_conv(2, std::integral_constant<int, 1>{}, a3);
+			gather_conv(3, std::integral_constant<int, 3>{}, a210);
 #pragma unroll
 			for (int i = 0; i < 4; i++) { S[3][i] = a3[0][i]; S[2][i] = a210[0][i]; S[1][i] = a210[1][i]; S[0][i] = a210[2][i]; }
 		}

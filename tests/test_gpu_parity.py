@@ -134,6 +134,42 @@ def test_batch_shapes(oracle):
     dec.close()
 
 
+@pytest.mark.parametrize("name,iters", [("cfg2_ems_u128", (8, 25)), ("cfg3_ems_u512", (12,))])
+def test_fixed_iterations_past_convergence_state_vs_oracle(oracle, name, iters):
+    """Fixed-iteration runs keep iterating codewords whose syndrome is already zero; on those the GF(256) EMS kernel builds short
+    lists from exact bounds instead of the full top-nm selection (nbl_cn_ems256.hip, `fast`).  Message state after iterations well
+    past convergence must still be bit-identical to the canonical oracle's -- golden frames (some converge early, some never), plus
+    strongly converging real-valued frames and integer-valued ones (exact ties at the thresholds and in the lists), fused and
+    unfused specialised kernels and the general kernel."""
+    g, meta = load_golden(name)
+    p, kw = meta["profile"], decoder_kwargs(meta["profile"])
+    code = nb.Code(meta["code"])
+    N, q = code.N, code.q
+    rng = np.random.default_rng(7)
+    Lg = g["L_ch"][:6]
+    strong = rng.normal(-14.0, 3.0, (3, N, q - 1))                # the all-zero codeword, reliably
+    ints = np.round(rng.normal(-12.0, 2.5, (3, N, q - 1)))         # the same on an integer grid
+    L = np.concatenate([Lg, strong, ints], axis=0)
+    for it in iters:
+        od = _oracle_decoder(oracle, meta, it, fixed=1)
+        ref = []
+        for b in range(L.shape[0]):
+            r, o, n_it = od.decode(L[b])
+            ref.append((r, o.copy(), n_it, [x.copy() for x in od.state()]))
+        assert sum(r for r, _, _, _ in ref) >= 6, "the batch must contain converged codewords"
+        for variant in (0, 2, 1):
+            dec = nb.Decoder(code, p["method"], int(it), fixed_iters=1, **kw)
+            _force_generic(dec, variant)
+            dec.record_state(True)
+            out, conv, n_its = dec.decode(L)
+            for b in range(L.shape[0]):
+                r, o, n_it, st = ref[b]
+                assert (conv[b], n_its[b]) == (r, n_it) and np.array_equal(out[b], o), (variant, it, b)
+                P, V, Cc = dec.read_state(b)
+                assert np.array_equal(P, st[0]) and np.array_equal(V, st[1]) and np.array_equal(Cc, st[2]), (variant, it, b)
+            dec.close()
+
+
 @pytest.mark.parametrize("codename,nm,nc", [("divsalar.UNBLDPC.128.64.GF.256", 16, 3), ("divsalar.UNBLDPC.128.64.GF.256", 16, 2),
                                             ("divsalar.UNBLDPC.128.64.GF.16", 8, 2)])
 def test_all_ties_and_erasures(oracle, codename, nm, nc):
