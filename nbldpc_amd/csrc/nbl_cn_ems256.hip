@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	// A codeword whose syndrome has been zero keeps iterating in fixed-iteration runs; its vectors have one dominant symbol each,
 	// which is where the short lists below pay (they are exact for any input -- the flag only decides whether the bounds are worth
 	// forming: on a codeword that is still searching they leave out next to nothing).
-	const bool tryf = NC >= 3 && r.fixed_iters && w.done[b];
+	const bool tryf = NC >= 2 && r.fixed_iters && w.done[b];
 #else
 	const bool tryf = false;
 #endif
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	// nA = end of the slot-0 run, n0 = end of the even symbols, nC = end of the slot-1 run
 	int n0[4] = {0, 0, 0, 0}, nA[4] = {0, 0, 0, 0}, nC[4] = {0, 0, 0, 0};
 	int cntl[4] = {nmr, nmr, nmr, nmr}; // entries per list
-	// Short lists (NC >= 3).  Output x already holds conf(q,1): S[x][s] >= flo[x] for every s.  A configuration for output x that
+	// Short lists.  Output x already holds conf(q,1): S[x][s] >= flo[x] for every s.  A configuration for output x that
 	// conf(q,1) does not already contain has two or more deviating edges, so beside any one of its entries (value v, edge a) the other
 	// two edges b, c contribute at most p_bc = max(m_b + sec_c, sec_b + m_c) (sec = best value beside rank 0): its sum is at most
 	// v + p_bc, up to rounding.  An entry with v + p_bc < flo[x] for every output x != a therefore cannot change anything, in any
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 	// list position of the lane's fixed operand: neighbouring lanes alternate between the front (even symbols) and the back (odd
 	// symbols) of the list -- a run of 16 even symbols would only reach half of the LDS banks of the scatter
 	const int apos = (lane & 1) ? (NM - 1) - ((lane & (NM - 1)) >> 1) : ((lane & (NM - 1)) >> 1);
-	auto pair_scatter = [&](double *dst, int ja, int jb, double bias, int sxor) {
+	auto pair_scatter = [&](double *dst, int ja, int jb, double bias, int sxor) __attribute__((always_inline)) {
 		WSYNC();
 		double2 ninf;
 		ninf.x = NBL_NEG_INF;
@@ -693,6 +693,12 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		ea.v = ea.v + bias;
 		ea.t8 ^= sxor << 3;
 		WSYNC();
+		if (fast) { // short lists: the moving operand stops at its last entry
+			for (int it = 0; it < ((cntl[jb] + PER - 1) >> (6 - LOGNM)); it++) {
+				const ListEnt eb = list_at(jb, it * PER + (lane >> LOGNM));
+				__hip_atomic_fetch_max((double *)((char *)dst + (ea.t8 ^ eb.t8)), ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		} else
 #pragma unroll
 		for (int it = 0; it < rounds; it++) {
 			const ListEnt eb = list_at(jb, it * PER + (lane >> LOGNM));
@@ -701,10 +707,16 @@ __global__ __launch_bounds__(64) void cn_ems_q256_dc4_kernel(NblGraphDev g, NblW
 		WSYNC();
 	};
 	// same, accumulating into dst without clearing it
-	auto pair_scatter_more = [&](double *dst, int ja, int jb, double bias, int sxor) {
+	auto pair_scatter_more = [&](double *dst, int ja, int jb, double bias, int sxor) __attribute__((always_inline)) {
 		ListEnt ea = list_at(ja, apos);
 		ea.v = ea.v + bias;
 		ea.t8 ^= sxor << 3;
+		if (fast) { // short lists: the moving operand stops at its last entry
+			for (int it = 0; it < ((cntl[jb] + PER - 1) >> (6 - LOGNM)); it++) {
+				const ListEnt eb = list_at(jb, it * PER + (lane >> LOGNM));
+				__hip_atomic_fetch_max((double *)((char *)dst + (ea.t8 ^ eb.t8)), ea.v + eb.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		} else
 #pragma unroll
 		for (int it = 0; it < rounds; it++) {
 			const ListEnt eb = list_at(jb, it * PER + (lane >> LOGNM));
