@@ -13,7 +13,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 code = nb.Code(CODE)
 ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dec = nb.Decoder(code, nb.METHOD_EMS, ITERS, ems_nm=32, ems_nc=3, fixed_iters=1, max_batch=B)
-L = synth_llr(torch, 256, 64, B, 1.0, 173, torch.device("cuda", 0)).cpu().numpy()
+EBN0 = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+L = synth_llr(torch, 256, 64, B, EBN0, 173, torch.device("cuda", 0)).cpu().numpy()
 dec.decode(L)
 lib = dec.lib
 lib.nbl_debug_stamps.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -34,7 +35,7 @@ print("total", tot / n, "cycles per check-wave (s_memtime ticks), samples", n)
 import json
 counts = dict(qs_trips_per_check=out[9] / n, inexact_edges_per_check=out[10] / n, un4_trips_per_check=out[11] / n, rem_trips_per_check=out[12] / n,
               short_list_checks_frac=out[13] / n, list_entries_per_check=out[14] / n, gather_entries_kept_per_check=out[3] / n,
-              batch=B, samples=int(n), workload=f"bench.py inputs (config 3, 1.0 dB), iteration 1..{ITERS} of a fixed-iteration decode")
+              batch=B, samples=int(n), workload=f"bench.py inputs (config 3, {EBN0} dB), iteration 1..{ITERS} of a fixed-iteration decode")
 print(json.dumps(counts))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(counts, open("gpurun_out/r03_stamps_counts.json", "w"), indent=1)
