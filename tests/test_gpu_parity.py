@@ -134,17 +134,21 @@ def test_batch_shapes(oracle):
     dec.close()
 
 
-@pytest.mark.parametrize("name,iters,nc", [("cfg2_ems_u128", (8, 25), None), ("cfg3_ems_u512", (12,), None), ("cfg2_ems_u128", (10,), 2),
-                                           ("cfg3_ems_u512", (9,), 2)])
-def test_fixed_iterations_past_convergence_state_vs_oracle(oracle, name, iters, nc):
+@pytest.mark.parametrize("name,iters,nc,nm", [("cfg2_ems_u128", (8, 25), None, None), ("cfg3_ems_u512", (12,), None, None),
+                                              ("cfg2_ems_u128", (10,), 2, None), ("cfg3_ems_u512", (9,), 2, None),
+                                              ("cfg2_ems_u128", (10,), 3, 8), ("cfg2_ems_u128", (10,), 3, 24), ("cfg2_ems_u128", (10,), 3, 64),
+                                              ("cfg2_ems_u128", (10,), 2, 5)])
+def test_fixed_iterations_past_convergence_state_vs_oracle(oracle, name, iters, nc, nm):
     """Fixed-iteration runs keep iterating codewords whose syndrome is already zero; on those the GF(256) EMS kernel builds short
     lists from exact bounds instead of the full top-nm selection (nbl_cn_ems256.hip, `fast`).  Message state after iterations well
     past convergence must still be bit-identical to the canonical oracle's -- golden frames (some converge early, some never), plus
     strongly converging real-valued frames and integer-valued ones (exact ties at the thresholds and in the lists), fused and
-    unfused specialised kernels and the general kernel."""
+    unfused specialised kernels and the general kernel; nc = 3 and 2, nm as a compile-time constant and at run time."""
     g, meta = load_golden(name)
-    if nc is not None:  # (the golden set's inputs, another deviation budget: the oracle is the reference here)
+    if nc is not None:  # (the golden set's inputs, another deviation budget / list length: the oracle is the reference here)
         meta = dict(meta, profile=dict(meta["profile"], ems_nc=nc))
+    if nm is not None:
+        meta = dict(meta, profile=dict(meta["profile"], ems_nm=nm))
     p, kw = meta["profile"], decoder_kwargs(meta["profile"])
     code = nb.Code(meta["code"])
     N, q = code.N, code.q
