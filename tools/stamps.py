@@ -34,7 +34,7 @@ print("total", tot / n, "cycles per check-wave (s_memtime ticks), samples", n)
 # run statistics for tools/isa_budget.py (gather_conv runs twice per check: the trips are per check, both calls together)
 import json
 counts = dict(qs_trips_per_check=out[9] / n, inexact_edges_per_check=out[10] / n, un4_trips_per_check=out[11] / n, rem_trips_per_check=out[12] / n,
-              short_list_checks_frac=out[13] / n, list_entries_per_check=out[14] / n, gather_entries_kept_per_check=out[3] / n,
+              short_list_checks_frac=out[13] / n, list_entries_per_check=out[14] / n,
               batch=B, samples=int(n), workload=f"bench.py inputs (config 3, {EBN0} dB), iteration 1..{ITERS} of a fixed-iteration decode")
 print(json.dumps(counts))
 os.makedirs("gpurun_out", exist_ok=True)
