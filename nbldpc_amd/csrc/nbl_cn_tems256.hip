@@ -125,12 +125,17 @@ __global__ __launch_bounds__(64, 4) void cn_tems_q256_dc4_kernel(NblGraphDev g, 
 		}
 		// most reliable symbol: strict '>' over ascending symbols from a running maximum of 0 (:1798-1807) = the lowest symbol
 		// that holds the maximum of {0, v[1..]}; symbol 0 (value 0) when nothing is positive
-		const double mx = wave_fmax_nonneg(dmax(dmax(v[0], v[1]), dmax(v[2], v[3]))); // (symbol 0 holds 0)
+		// (symbol 0 holds 0; nothing positive -- every vector of a converged all-zero codeword -- is settled by one compare)
+		const double lmx = dmax(dmax(v[0], v[1]), dmax(v[2], v[3]));
+		double mx = 0.0;
 		int arg = 0;
+		if (__ballot(lmx > 0.0)) {
+			mx = wave_fmax_nonneg(lmx);
 #pragma unroll
-		for (int i = NS - 1; i >= 0; i--) {
-			const uint64_t hit = __ballot(v[i] == mx);
-			arg = hit ? 64 * i + __builtin_ctzll(hit) : arg;
+			for (int i = NS - 1; i >= 0; i--) {
+				const uint64_t hit = __ballot(v[i] == mx);
+				arg = hit ? 64 * i + __builtin_ctzll(hit) : arg;
+			}
 		}
 		mh[d].init(g.c_h[c0 + d], g.poly, lane);
 		int bd = 0;

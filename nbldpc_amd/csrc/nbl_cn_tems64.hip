@@ -109,9 +109,15 @@ __global__ __launch_bounds__(64) void cn_tems_q64_dc4_kernel(NblGraphDev g, NblW
 			}
 			double nv = lane == 0 ? 0.0 : post[0] - (ownA[d] ? ca[d] : cb[d]);
 			// DecideLLRVector of the new vector (:1542-1562): lowest symbol among the maxima of {0, nv[1..]}
-			double mx = wave_fmax_nonneg(nv); // (lane 0 holds 0)
-			uint64_t hit = __ballot(nv == mx);
-			int arg = hit ? __builtin_ctzll(hit) : 0;
+			// (lane 0 holds 0; nothing positive -- every vector of a converged all-zero codeword -- is settled by one compare: maximum 0 at symbol 0)
+			double mx = 0.0;
+			int arg = 0;
+			uint64_t hit;
+			if (__ballot(nv > 0.0)) {
+				mx = wave_fmax_nonneg(nv);
+				hit = __ballot(nv == mx);
+				arg = hit ? __builtin_ctzll(hit) : 0;
+			}
 			int bef = uniform(before[d]);
 			if (first) {
 				const double old[1] = {ov[d]};

@@ -217,6 +217,7 @@ template <int NS> __device__ __forceinline__ int wave_decide(const double (&v)[N
 #pragma unroll
 	for (int i = 0; i < NS; i++)
 		if (lane + 64 * i < q) best = dmax(best, v[i]);
+	if (!__ballot(best > 0.0)) return 0; // nothing positive: every lane's running maximum is still the initial 0 (one compare, no reduction)
 	const double mx = wave_fmax_nonneg(best);
 	int arg = 0;
 #pragma unroll
@@ -224,7 +225,7 @@ template <int NS> __device__ __forceinline__ int wave_decide(const double (&v)[N
 		const uint64_t hit = __ballot(lane + 64 * i < q && v[i] == mx);
 		arg = hit ? 64 * i + __builtin_ctzll(hit) : arg;
 	}
-	return mx > 0.0 ? arg : 0;
+	return arg; // (mx > 0 here)
 }
 
 // The same decision with the reduction on 32-bit keys: a vector without a positive entry decides 0 after one compare (every
