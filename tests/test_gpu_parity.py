@@ -156,7 +156,11 @@ def test_fixed_iterations_past_convergence_state_vs_oracle(oracle, name, iters, 
     Lg = g["L_ch"][:6]
     strong = rng.normal(-14.0, 3.0, (3, N, q - 1))                # the all-zero codeword, reliably
     ints = np.round(rng.normal(-12.0, 2.5, (3, N, q - 1)))         # the same on an integer grid
-    L = np.concatenate([Lg, strong, ints], axis=0)
+    # zero syndrome from the first iteration on, yet nothing dominant: all-negative vectors with small gaps (integers: exact ties at
+    # the thresholds; reals: entries a hair above and below them) -- the bounds are formed on every check and must admit all they need
+    weak_i = -1.0 - np.abs(np.round(rng.normal(0.0, 1.5, (3, N, q - 1))))
+    weak_r = -0.05 - np.abs(rng.normal(0.0, 1.0, (3, N, q - 1)))
+    L = np.concatenate([Lg, strong, ints, weak_i, weak_r], axis=0)
     for it in iters:
         od = _oracle_decoder(oracle, meta, it, fixed=1)
         ref = []
