@@ -18,6 +18,10 @@ Rank 0 prints ONE JSON line.  Extra objects:
   cpu_baseline  the compiled reference itself (oracle/_ref, kind "reference") on this host's cores, decode loop only, on a
                 bounded sample of the same workload (rank 0, N=1 only); cpu_baseline_port = the oracle's literal restatement
                 on codewords of the same batch (kind "port"; also the fallback when oracle/_ref is absent)
+
+`headline_by_convergence` (rank 0, N = 1): the headline configuration once at 0 dB (no codeword converges: every check on the full
+path) and once at 2 dB (all converge: exact short lists) -- the kernel's rate depends on how many of the batch's
+codewords are past convergence, and the bench's 1 dB sits between the two.
 """
 import argparse
 import json
@@ -300,6 +304,14 @@ def main():
         del L, out, conv, its, tx_dev
         torch.cuda.empty_cache()
         res["other_configs"] = other_configs(local_rank)
+        # The headline kernel does less on codewords whose syndrome is already zero (exact short lists): the same
+        # configuration where nothing converges (every check on the full path) and where everything does, one short pass each
+        import bench_config
+        res["headline_by_convergence"] = []
+        for e in (0.0, 2.0):
+            rr = bench_config.run_config("cfg3", B, 1, e, local_rank)
+            res["headline_by_convergence"].append({"ebn0_dB": e, "value": rr["codewords_per_s"], "unit": "codewords/s", "converged_frac": rr["converged_frac"],
+                                                   "ms_per_launch": rr["cn_ms_per_launch"], "data": "synthetic (all-zero codeword + randn noise)"})
     if rank == 0:
         print(json.dumps(res))
     ranks.finish(rk)
