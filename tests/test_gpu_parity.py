@@ -181,6 +181,48 @@ def test_fixed_iterations_past_convergence_state_vs_oracle(oracle, name, iters, 
             dec.close()
 
 
+def _bpsk_llr_zero(rng, code, B, ebn0_db):
+    """Symbol LLRs of the all-zero codeword over BPSK / AWGN at rate 1/2 (Comm.cpp:176-177, :340-407)."""
+    p = code.q.bit_length() - 1
+    sigma = 1.0 / np.sqrt(2 * 0.5 * 10 ** (ebn0_db / 10.0))
+    bit = -2.0 * (1.0 + sigma * rng.standard_normal((B, code.N, p))) / sigma ** 2
+    a = np.arange(1, code.q)
+    mask = ((a[:, None] >> np.arange(p)[None, :]) & 1).astype(np.float64)
+    return bit @ mask.T
+
+
+@pytest.mark.parametrize("case", ["ems256", "ems256_nc2", "tems256", "tems64"])
+def test_exact_bounds_state_fuzz_fixed_iterations(oracle, case):
+    """The exact bounds of the EMS GF(256) kernel (short lists on codewords past convergence) and of the T-EMS kernels (candidates no
+    check sum can use) must never change a message: fixed-iteration decodes of channel frames across the waterfall -- frames that
+    converge at once, late or never -- with the message state of EVERY frame compared bit for bit with the canonical oracle."""
+    codename, meth, ometh, kw, its, per = {
+        "ems256": ("divsalar.UNBLDPC.128.64.GF.256", nb.METHOD_EMS, oracle.EMS, dict(ems_nm=16, ems_nc=3), 14, 12),
+        "ems256_nc2": ("divsalar.UNBLDPC.128.64.GF.256", nb.METHOD_EMS, oracle.EMS, dict(ems_nm=12, ems_nc=2, ems_factor=1.1, ems_offset=0.1), 12, 8),
+        "tems256": ("divsalar.UNBLDPC.128.64.GF.256", nb.METHOD_TEMS, oracle.TEMS, dict(tems_nr=2, tems_nc=3), 6, 3),
+        "tems64": ("BDS.576.288.GF.64", nb.METHOD_TEMS, oracle.TEMS, dict(tems_nr=2, tems_nc=3), 7, 3),
+    }[case]
+    code = nb.Code(codename)
+    N, M, q, ev, ec, eh = df.code_edges(codename)
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    L = np.concatenate([_bpsk_llr_zero(rng, code, per, e) for e in (1.0, 2.0, 3.0, 4.5)], axis=0)
+    L[1::4] = np.round(L[1::4])  # every fourth frame on an integer grid: exact ties
+    od = oracle.Decoder(oracle.Code(edges=(N, M, q, ev, ec, eh)), oracle.GF(q), ometh, its, oracle.CANONICAL, fixed_iters=1, **kw)
+    dec = nb.Decoder(code, meth, its, fixed_iters=1, **kw)
+    dec.record_state(True)
+    out, conv, n_its = dec.decode(L)
+    n_conv = 0
+    for b in range(L.shape[0]):
+        r, o, n_it = od.decode(L[b])
+        n_conv += r
+        assert (conv[b], n_its[b]) == (r, n_it) and np.array_equal(out[b], o), (case, b)
+        P, V, Cc = dec.read_state(b)
+        oP, oV, oC = od.state()
+        assert np.array_equal(P, oP) and np.array_equal(V, oV) and np.array_equal(Cc, oC), (case, b)
+    dec.close()
+    assert 0 < n_conv < L.shape[0], "the batch must mix converged and unconverged codewords"
+
+
 @pytest.mark.parametrize("codename,nm,nc", [("divsalar.UNBLDPC.128.64.GF.256", 16, 3), ("divsalar.UNBLDPC.128.64.GF.256", 16, 2),
                                             ("divsalar.UNBLDPC.128.64.GF.16", 8, 2)])
 def test_all_ties_and_erasures(oracle, codename, nm, nc):
