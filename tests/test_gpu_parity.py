@@ -204,7 +204,7 @@ def test_exact_bounds_state_fuzz_fixed_iterations(oracle, case):
     }[case]
     code = nb.Code(codename)
     N, M, q, ev, ec, eh = df.code_edges(codename)
-    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    rng = np.random.default_rng({"ems256": 11, "ems256_nc2": 12, "tems256": 13, "tems64": 14}[case])
     L = np.concatenate([_bpsk_llr_zero(rng, code, per, e) for e in (1.0, 2.0, 3.0, 4.5)], axis=0)
     L[1::4] = np.round(L[1::4])  # every fourth frame on an integer grid: exact ties
     od = oracle.Decoder(oracle.Code(edges=(N, M, q, ev, ec, eh)), oracle.GF(q), ometh, its, oracle.CANONICAL, fixed_iters=1, **kw)
