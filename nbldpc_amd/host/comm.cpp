@@ -239,34 +239,42 @@ static void crc_taps(int len, int type24, int G[25])
 	else if (len == 24) { const int t[] = {0, 1, 5, 6, 23, 24}; for (int x : t) G[x] = 1; }
 }
 
+// The shift registers of Comm.cpp:506-636 as one integer: bit j = reg[j]; a clock is a shift and, when the feedback bit is set, an
+// XOR with the tap mask (bit j set for G[j], j = 0 .. len-1) -- the same register contents as the reference's inner loop over j.
+static unsigned crc_mask(int len, int type24)
+{
+	int G[25];
+	crc_taps(len, type24, G);
+	unsigned m = 0;
+	for (int j = 0; j < len; j++) m |= (unsigned)(G[j] != 0) << j;
+	return m;
+}
+
 void CComm::CRCEncode(int *out, const int *in, int n, int len, int type24) // Comm.cpp:506-561
 {
 	if (in != out) memcpy(out, in, sizeof(int) * n);
 	if (len == 0) return;
-	int G[25], reg[24] = {0};
-	crc_taps(len, type24, G);
+	const unsigned taps = crc_mask(len, type24), keep = (len == 32) ? 0xffffffffu : ((1u << len) - 1u);
+	unsigned reg = 0;
 	for (int i = 0; i < n; i++) {
-		const int fb = reg[len - 1] ^ in[i];
-		for (int j = len - 1; j > 0; j--) reg[j] = reg[j - 1] ^ (G[j] && fb);
-		reg[0] = fb;
+		const unsigned fb = ((reg >> (len - 1)) ^ (unsigned)in[i]) & 1u; // reg[len-1] ^ in[i]; reg[0] = fb (G[0] = 1)
+		reg = ((reg << 1) & keep) ^ (fb ? taps : 0u);
 	}
-	for (int i = 0; i < len; i++) out[n + i] = reg[len - 1 - i];
+	for (int i = 0; i < len; i++) out[n + i] = (int)((reg >> (len - 1 - i)) & 1u);
 }
 
 int CComm::CrcCheck(const int *in, int n, int len, int type24) // Comm.cpp:564-636
 {
 	if (len == 0) return 1;
-	int G[25], reg[24] = {0}, ones = 0;
-	crc_taps(len, type24, G);
+	const unsigned taps = crc_mask(len, type24), keep = (len == 32) ? 0xffffffffu : ((1u << len) - 1u);
+	unsigned reg = 0;
+	int ones = 0;
 	for (int i = 0; i < n; i++) {
-		const int fb = reg[len - 1];
-		for (int j = len - 1; j > 0; j--) reg[j] = reg[j - 1] ^ (G[j] && fb);
-		reg[0] = fb ^ in[i];
+		const unsigned fb = (reg >> (len - 1)) & 1u;                      // reg[len-1]; reg[0] = fb ^ in[i]
+		reg = (((reg << 1) & keep) ^ (fb ? taps : 0u)) ^ ((unsigned)in[i] & 1u);
 		ones += in[i];
 	}
-	int rem = 0;
-	for (int i = 0; i < len; i++) rem += reg[i];
-	return (rem == 0 && ones != 0) ? 1 : 0; // an all-zero word does not count as a CRC pass
+	return (reg == 0 && ones != 0) ? 1 : 0; // an all-zero word does not count as a CRC pass
 }
 
 int CComm::Encode() // Comm.cpp:255-289
