@@ -116,10 +116,30 @@ int CComm::FrontEndToChannel()
 
 int CComm::FrontEndToModulate(unsigned int state_out[3])
 {
+	// Nothing after this call reads the chain's intermediates (message bits in front of the CRC, code symbols and bits, modulator
+	// bits, constellation points): only TX_MSG_BIT / TX_MSG_SYM (error count) and TX_MOD_IDX (shipped to the device) are kept.  With
+	// thousands of lanes per thread the intermediates of a lane are cold every cycle -- 14 KB of cache misses per frame, five times
+	// the chain's arithmetic -- so they are swapped (pointer swaps) for one set of per-thread buffers that stays in the cache.
+	struct Scratch { std::vector<int> before_crc, code_sym, code_bit, mod_bit; std::vector<CComplex> mod_sym; };
+	static thread_local Scratch tl;
+	if (tl.before_crc.size() != TX_MSG_BIT_beforeCRC.size()) tl.before_crc.assign(TX_MSG_BIT_beforeCRC.size(), 0);
+	if (tl.code_sym.size() != TX_CODE_SYM.size()) tl.code_sym.assign(TX_CODE_SYM.size(), 0);
+	if (tl.code_bit.size() != TX_CODE_BIT.size()) tl.code_bit.assign(TX_CODE_BIT.size(), 0);
+	if (tl.mod_bit.size() != TX_MOD_BIT.size()) tl.mod_bit.assign(TX_MOD_BIT.size(), 0);
+	if (tl.mod_sym.size() != TX_MOD_SYM.size()) tl.mod_sym.assign(TX_MOD_SYM.size(), CComplex());
+	auto exchange = [&] {
+		TX_MSG_BIT_beforeCRC.swap(tl.before_crc);
+		TX_CODE_SYM.swap(tl.code_sym);
+		TX_CODE_BIT.swap(tl.code_bit);
+		TX_MOD_BIT.swap(tl.mod_bit);
+		TX_MOD_SYM.swap(tl.mod_sym);
+	};
+	exchange();
 	GenerateMessage();
 	Encode();
 	Puncture();
 	Modulate();
+	exchange();
 	state_out[0] = (unsigned int)(Rand.IX % 61967ul);
 	state_out[1] = (unsigned int)(Rand.IY % 63443ul);
 	state_out[2] = (unsigned int)(Rand.IZ % 63599ul);
